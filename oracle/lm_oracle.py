@@ -1,0 +1,157 @@
+"""ctypes front-end of the CPU oracle (oracle/lm_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+the product package geocalib_amd never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_BUILD = os.path.join(_HERE, "_build")
+CAMERA_MODELS = {"pinhole": 0, "simple_radial": 1, "radial": 2, "simple_divisional": 3}
+MAXP = 5
+
+DEFAULT_CONF = {  # lm_optimizer.py:144-162
+    "camera_model": "pinhole", "shared_intrinsics": False, "num_steps": 30, "lambda_": 0.1,
+    "fix_lambda": False, "early_stop": True, "atol": 1e-8, "rtol": 1e-8,
+    "use_spherical_manifold": True, "use_log_focal": True,
+    "up_loss_fn_scale": 1e-2, "lat_loss_fn_scale": 1e-2, "verbose": False,
+}
+
+
+class _Conf(C.Structure):
+    _fields_ = [("camera_model", C.c_int), ("shared_intrinsics", C.c_int), ("num_steps", C.c_int),
+                ("lambda0", C.c_double), ("fix_lambda", C.c_int), ("early_stop", C.c_int),
+                ("atol", C.c_double), ("rtol", C.c_double), ("use_spherical_manifold", C.c_int),
+                ("use_log_focal", C.c_int), ("up_loss_fn_scale", C.c_double),
+                ("lat_loss_fn_scale", C.c_double), ("training", C.c_int), ("num_threads", C.c_int)]
+
+
+_FP = C.POINTER(C.c_float)
+
+
+class _Data(C.Structure):
+    _fields_ = [("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("up", _FP), ("lat", _FP),
+                ("up_conf", _FP), ("lat_conf", _FP), ("scales", _FP), ("prior_focal", _FP),
+                ("prior_gravity", _FP), ("prior_dist", _FP)]
+
+
+def build(force: bool = False) -> None:
+    """Compile the oracle with gcc (idempotent)."""
+    outs = [os.path.join(_BUILD, f"liblm_oracle_{p}.so") for p in ("f32", "f64")]
+    src = os.path.join(_HERE, "lm_oracle.c")
+    if not force and all(os.path.exists(o) and os.path.getmtime(o) >= os.path.getmtime(src) for o in outs):
+        return
+    subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True, capture_output=True)
+
+
+_libs = {}
+
+
+def _lib(precision: str):
+    if precision not in _libs:
+        path = os.path.join(_BUILD, f"liblm_oracle_{precision}.so")
+        if not os.path.exists(path):
+            build()
+        lib = C.CDLL(path)
+        lib.lm_oracle_solve.restype = C.c_int
+        lib.lm_oracle_system.restype = C.c_int
+        _libs[precision] = lib
+    return _libs[precision]
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+def _ptr(a):
+    return C.cast(None, _FP) if a is None else a.ctypes.data_as(_FP)
+
+
+def _pack(conf, data, training=False, num_threads=0):
+    cf = {**DEFAULT_CONF, **(conf or {})}
+    c = _Conf(CAMERA_MODELS[cf["camera_model"]], int(cf["shared_intrinsics"]), int(cf["num_steps"]),
+              float(cf["lambda_"]), int(cf["fix_lambda"]), int(cf["early_stop"]), float(cf["atol"]),
+              float(cf["rtol"]), int(cf["use_spherical_manifold"]), int(cf["use_log_focal"]),
+              float(cf["up_loss_fn_scale"]), float(cf["lat_loss_fn_scale"]), int(training),
+              int(num_threads))
+    keep = {k: _f32(data.get(k)) for k in ("up_field", "latitude_field", "up_confidence",
+                                           "latitude_confidence", "scales", "prior_focal",
+                                           "prior_gravity", "prior_dist")}
+    ref = keep["up_field"] if keep["up_field"] is not None else keep["latitude_field"]
+    B, _, H, W = ref.shape
+    d = _Data(B, H, W, _ptr(keep["up_field"]), _ptr(keep["latitude_field"]),
+              _ptr(keep["up_confidence"]), _ptr(keep["latitude_confidence"]), _ptr(keep["scales"]),
+              _ptr(keep["prior_focal"]), _ptr(keep["prior_gravity"]), _ptr(keep["prior_dist"]))
+    return cf, c, d, keep, (B, H, W)
+
+
+def solve(data: dict, conf: dict = None, precision: str = "f32", training: bool = False,
+          num_threads: int = 0, trace: bool = False) -> dict:
+    """Run the restated LMOptimizer.forward (lm_optimizer.py:646-664) on numpy inputs.
+
+    data keys follow the reference: up_field (B,2,H,W), latitude_field (B,1,H,W), up_confidence,
+    latitude_confidence (B,H,W), scales (2,), prior_focal (B,), prior_gravity (B,3), prior_dist (B,nd).
+    Returns numpy arrays keyed like the reference's output dict (camera -> (B,8), gravity -> (B,3)).
+    """
+    lib = _lib(precision)
+    cf, c, d, keep, (B, H, W) = _pack(conf, data, training, num_threads)
+    stride = lib.lm_oracle_info_stride()
+    cam = np.zeros((B, 8), np.float32)
+    grav = np.zeros((B, 3), np.float32)
+    info = np.zeros((B, stride), np.float32)
+    tr = None
+    if trace:
+        tr = np.zeros((cf["num_steps"], B, lib.lm_oracle_trace_stride()), np.float64)
+    rc = lib.lm_oracle_solve(C.byref(c), C.byref(d), _ptr(cam), _ptr(grav), _ptr(info),
+                             tr.ctypes.data_as(C.POINTER(C.c_double)) if trace else None)
+    if rc != 0:
+        raise RuntimeError(f"lm_oracle_solve failed: {rc}")
+    P = int(info[0, 12])
+    out = {"camera": cam, "gravity": grav, "stop_at": info[:, 0].copy(),
+           "initial_up_cost": info[:, 1].copy(), "initial_latitude_cost": info[:, 2].copy(),
+           "initial_cost": info[:, 3].copy(), "final_up_cost": info[:, 4].copy(),
+           "final_latitude_cost": info[:, 5].copy(), "final_cost": info[:, 6].copy(),
+           "lambda": info[:, 13].copy()}
+    if not training:
+        out.update({"covariance": info[:, 16:16 + P * P].reshape(B, P, P).copy(),
+                    "roll_uncertainty": info[:, 7].copy(), "pitch_uncertainty": info[:, 8].copy(),
+                    "gravity_uncertainty": info[:, 9].copy(), "focal_uncertainty": info[:, 10].copy(),
+                    "vfov_uncertainty": info[:, 11].copy()})
+    if trace:
+        out["trace"] = {"cost_up": tr[..., 0], "cost_lat": tr[..., 1], "lambda": tr[..., 2],
+                        "G": tr[..., 3:8], "H": tr[..., 8:33].reshape(tr.shape[0], B, 5, 5),
+                        "delta": tr[..., 33:38], "cam": tr[..., 38:42], "gravity": tr[..., 42:45]}
+    return out
+
+
+def system(data: dict, camera: np.ndarray, gravity: np.ndarray, conf: dict = None,
+           as_rpf: bool = False, precision: str = "f32") -> dict:
+    """One sweep at fixed parameters: mean Huber costs, J^T W r and J^T W J per image."""
+    lib = _lib(precision)
+    cf, c, d, keep, (B, H, W) = _pack(conf, data)
+    cam, grav = _f32(camera).reshape(B, 8), _f32(gravity).reshape(B, 3)
+    cu, cl = np.zeros(B), np.zeros(B)
+    G, Hm = np.zeros((B, MAXP)), np.zeros((B, MAXP, MAXP))
+    dp = C.POINTER(C.c_double)
+    P = lib.lm_oracle_system(C.byref(c), C.byref(d), _ptr(cam), _ptr(grav), int(as_rpf),
+                             cu.ctypes.data_as(dp), cl.ctypes.data_as(dp), G.ctypes.data_as(dp),
+                             Hm.ctypes.data_as(dp))
+    return {"cost_up": cu, "cost_lat": cl, "G": G[:, :P].copy(), "H": Hm[:, :P, :P].copy()}
+
+
+def render(camera_model: str, H: int, W: int, camera: np.ndarray, gravity: np.ndarray,
+           precision: str = "f64"):
+    """Perspective field of each (camera, gravity): up (B,2,H,W), lat (B,1,H,W) (perspective_fields.py:278)."""
+    lib = _lib(precision)
+    cam, grav = _f32(camera).reshape(-1, 8), _f32(gravity).reshape(-1, 3)
+    B = cam.shape[0]
+    up = np.zeros((B, 2, H, W), np.float32)
+    lat = np.zeros((B, 1, H, W), np.float32)
+    for b in range(B):
+        lib.lm_oracle_render(CAMERA_MODELS[camera_model], H, W, _ptr(cam[b]), _ptr(grav[b]),
+                             _ptr(up[b]), _ptr(lat[b]))
+    return up, lat
