@@ -1,0 +1,91 @@
+"""ctypes binding of libgeocalib_hip.so (C ABI: include/gclm.h).
+
+There is no CPU fallback: if the shared library is missing or no HIP device is visible the
+product path raises.  Build the library with `python __graft_entry__.py` (or `make -C
+geocalib_amd/csrc`); it is kept in-tree at geocalib_amd/lib/libgeocalib_hip.so.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgeocalib_hip.so")
+
+CAMERA_MODEL_IDS = {"pinhole": 0, "simple_radial": 1, "radial": 2, "simple_divisional": 3}
+INFO_STRIDE = 48
+SHARED_PARTIAL_STRIDE = 16
+MAX_PARAMS = 5
+INFO = {"stop_at": 0, "initial_up_cost": 1, "initial_latitude_cost": 2, "initial_cost": 3,
+        "final_up_cost": 4, "final_latitude_cost": 5, "final_cost": 6, "roll_uncertainty": 7,
+        "pitch_uncertainty": 8, "gravity_uncertainty": 9, "focal_uncertainty": 10,
+        "vfov_uncertainty": 11, "n_params": 12, "lambda": 13, "step_failures": 14, "covariance": 16}
+
+
+class GclmConfig(C.Structure):
+    """struct gclm_config (include/gclm.h)."""
+
+    _fields_ = [("camera_model", C.c_int32), ("shared_intrinsics", C.c_int32),
+                ("group_size", C.c_int32), ("num_steps", C.c_int32), ("lambda0", C.c_float),
+                ("fix_lambda", C.c_int32), ("early_stop", C.c_int32), ("atol", C.c_float),
+                ("rtol", C.c_float), ("use_spherical_manifold", C.c_int32),
+                ("use_log_focal", C.c_int32), ("up_loss_fn_scale", C.c_float),
+                ("lat_loss_fn_scale", C.c_float), ("estimate_gravity", C.c_int32),
+                ("estimate_focal", C.c_int32), ("estimate_dist", C.c_int32),
+                ("compute_uncertainty", C.c_int32)]
+
+    def key(self):
+        return tuple(getattr(self, f) for f, _ in self._fields_)
+
+
+class GclmError(RuntimeError):
+    """A gclm_* entry point returned a non-zero code."""
+
+
+_lib = None
+
+_P = C.c_void_p
+_SIGNATURES = {
+    "gclm_version": (C.c_int, []),
+    "gclm_default_config": (C.c_int, [C.POINTER(GclmConfig)]),
+    "gclm_create": (C.c_int, [C.POINTER(_P), C.POINTER(GclmConfig), C.c_int]),
+    "gclm_configure": (C.c_int, [_P, C.POINTER(GclmConfig)]),
+    "gclm_destroy": (C.c_int, [_P]),
+    "gclm_last_error": (C.c_char_p, [_P]),
+    "gclm_workspace_bytes": (C.c_size_t, [_P]),
+    "gclm_solve": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "gclm_system": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P]),
+    "gclm_shared_begin": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P]),
+    "gclm_shared_reduce": (C.c_int, [_P, C.c_int, _P, _P]),
+    "gclm_shared_apply": (C.c_int, [_P, C.c_int, _P, _P]),
+    "gclm_shared_finish": (C.c_int, [_P, _P, _P]),
+    "gclm_synth_fields": (C.c_int, [C.c_int, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float,
+                                    _P, _P, _P, _P, _P, _P, _P]),
+    "gclm_set_timing": (C.c_int, [_P, C.c_int]),
+    "gclm_last_pass_timing": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def load():
+    """Load libgeocalib_hip.so (once).  Raises if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: the HIP extension is not built (run `python __graft_entry__.py` "
+                "or `make -C geocalib_amd/csrc`). geocalib_amd has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def last_error(handle=None) -> str:
+    msg = load().gclm_last_error(handle)
+    return msg.decode() if msg else ""
+
+
+def check(rc: int, handle=None, what: str = "gclm"):
+    if rc != 0:
+        raise GclmError(f"{what} failed ({rc}): {last_error(handle)}")

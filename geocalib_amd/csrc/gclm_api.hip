@@ -1,0 +1,401 @@
+// gclm_api.hip -- C ABI of libgeocalib_hip.so (include/gclm.h) and the launch sequence of a solve.
+//
+// A solve is 2*num_steps+4 asynchronous launches on the caller's stream and no host round trip:
+//   init | { sweep(theta_i) ; update_i [; decide_i] } x num_steps | prep_final ; sweep(theta_final, rpf) ; finalize
+// (the reference syncs twice per step: H,G -> CPU Cholesky -> device, and torch.allclose).
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "gclm_internal.h"
+
+using namespace gclm;
+
+struct gclm_handle {
+    gclm_config cfg;
+    int device = 0;
+    std::string err;
+    // device scratch (owned)
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    // carved views
+    SolveCtx ctx{};
+    float* group_partials = nullptr;
+    // split shared-intrinsics session
+    struct {
+        bool active = false;
+        const float *up = nullptr, *lat = nullptr, *upc = nullptr, *latc = nullptr;
+        float *cam_io = nullptr, *grav_io = nullptr;
+        Geometry geo{};
+    } sh;
+    // optional timing of the sweep launches
+    bool timing = false;
+    std::vector<hipEvent_t> ev;
+    int ev_used = 0;
+};
+
+namespace {
+
+std::string g_create_error;
+
+int fail(gclm_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define GCLM_HIP(h, expr)                                                                   \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) return fail(h, -10, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+const char* validate(const gclm_config& c) {
+    if (c.camera_model != GCLM_PINHOLE && c.camera_model != GCLM_SIMPLE_RADIAL)
+        return "camera_model: only pinhole (0) and simple_radial (1) are implemented by the HIP path";
+    if (c.num_steps < 0 || c.num_steps > GCLM_MAX_STEPS) return "num_steps out of range [0, GCLM_MAX_STEPS]";
+    if (!(c.up_loss_fn_scale > 0.f) || !(c.lat_loss_fn_scale > 0.f)) return "loss scales must be > 0";
+    if (c.group_size < 0) return "group_size must be >= 0";
+    if (c.shared_intrinsics && !(c.estimate_gravity && c.estimate_focal))
+        return "shared_intrinsics requires gravity and focal to be estimated (lm_optimizer.py:350-383)";
+    if (c.shared_intrinsics && c.camera_model != GCLM_PINHOLE && !c.estimate_dist)
+        return "shared_intrinsics with a distortion prior is not supported";
+    const int n = 2 * (c.estimate_gravity != 0) + (c.estimate_focal != 0) + (c.camera_model != GCLM_PINHOLE);
+    if (n == 0) return "No parameters to optimize";
+    return nullptr;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+bool is_aligned16(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Carve the workspace for B images / nchunks partial records per image / G groups.
+int ensure_workspace(gclm_handle* h, int B, int nchunks, int G) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_state0 = take(sizeof(State) * B), o_state1 = take(sizeof(State) * B);
+    const size_t o_pb0 = take(sizeof(PBlock) * B), o_pb1 = take(sizeof(PBlock) * B), o_pbf = take(sizeof(PBlock) * B);
+    const size_t o_part = take(sizeof(float) * kNAcc * (size_t)B * nchunks);
+    const size_t o_fsys = take(sizeof(float) * kNAcc * (size_t)B);
+    const size_t o_gp = take(sizeof(float) * GCLM_SHARED_PARTIAL_STRIDE * (size_t)(G > 0 ? G : 1));
+    const size_t o_ctrl = take(sizeof(Ctrl));
+    if (off > h->ws_bytes) {
+        if (h->ws) GCLM_HIP(h, hipFree(h->ws));
+        h->ws = nullptr;
+        h->ws_bytes = 0;
+        const size_t want = off + off / 4;      // headroom: no reallocation for slightly larger calls
+        GCLM_HIP(h, hipMalloc(&h->ws, want));
+        h->ws_bytes = want;
+    }
+    char* base = static_cast<char*>(h->ws);
+    SolveCtx& c = h->ctx;
+    c.state[0] = reinterpret_cast<State*>(base + o_state0);
+    c.state[1] = reinterpret_cast<State*>(base + o_state1);
+    c.pb[0] = reinterpret_cast<PBlock*>(base + o_pb0);
+    c.pb[1] = reinterpret_cast<PBlock*>(base + o_pb1);
+    c.pb_final = reinterpret_cast<PBlock*>(base + o_pbf);
+    c.partials = reinterpret_cast<float*>(base + o_part);
+    c.frame_sys = reinterpret_cast<float*>(base + o_fsys);
+    c.ctrl = reinterpret_cast<Ctrl*>(base + o_ctrl);
+    h->group_partials = reinterpret_cast<float*>(base + o_gp);
+    return 0;
+}
+
+SweepArgs sweep_args(const gclm_handle* h, const float* up, const float* lat, const float* upc, const float* latc,
+                     const PBlock* pb, const Geometry& g, bool skip) {
+    SweepArgs a{};
+    a.up = up; a.lat = lat; a.upc = up ? upc : nullptr; a.latc = latc;
+    a.pb = pb; a.ctrl = h->ctx.ctrl; a.partials = h->ctx.partials;
+    a.B = h->ctx.B; a.H = h->ctx.H; a.W = h->ctx.W;
+    a.nchunks = g.nchunks; a.units_per_block = g.units_per_block; a.vec = g.vec;
+    a.skip_if_stopped = skip ? 1 : 0;
+    a.up_scale = h->cfg.up_loss_fn_scale; a.lat_scale = h->cfg.lat_loss_fn_scale;
+    return a;
+}
+
+int timed_sweep(gclm_handle* h, const SweepArgs& a, hipStream_t s) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->timing) {
+        while ((int)h->ev.size() < h->ev_used + 2) {
+            hipEvent_t e;
+            GCLM_HIP(h, hipEventCreate(&e));
+            h->ev.push_back(e);
+        }
+        e0 = h->ev[h->ev_used];
+        e1 = h->ev[h->ev_used + 1];
+        h->ev_used += 2;
+        GCLM_HIP(h, hipEventRecord(e0, s));
+    }
+    GCLM_HIP(h, launch_sweep(h->cfg.camera_model, a, s));
+    if (h->timing) GCLM_HIP(h, hipEventRecord(e1, s));
+    return 0;
+}
+
+int check_shapes(gclm_handle* h, const float* lat, int B, int H, int W) {
+    if (!lat) return fail(h, -3, "latitude_field is required (lm_optimizer.py:31 raises KeyError without it)");
+    if (B < 0 || H <= 0 || W <= 0) return fail(h, -3, "bad shape B=%d H=%d W=%d", B, H, W);
+    if ((size_t)H * W >= (size_t)1 << 30) return fail(h, -3, "image too large");
+    return 0;
+}
+
+int setup_groups(gclm_handle* h, int B) {
+    SolveCtx& c = h->ctx;
+    c.group_of_frame = nullptr;
+    if (!h->cfg.shared_intrinsics) { c.n_groups = 0; c.group_size = 1; return 0; }
+    const int gs = h->cfg.group_size > 0 ? h->cfg.group_size : (B > 0 ? B : 1);
+    if (B % gs != 0) return fail(h, -3, "batch %d is not a multiple of group_size %d", B, gs);
+    c.group_size = gs;
+    c.n_groups = B / gs;
+    return 0;
+}
+
+}  // namespace
+
+namespace gclm {
+Geometry plan_geometry(int B, int H, int W, bool aligned16) {
+    Geometry g;
+    const size_t N = (size_t)H * W;
+    g.vec = (aligned16 && (W % 4 == 0)) ? 4 : 1;
+    g.units = (int)(N / g.vec);
+    // ~20 loop iterations per thread amortise the 16-value workgroup reduction; fewer when the
+    // batch alone cannot fill 256 CUs x 4+ workgroups.
+    int iters = 20;
+    auto chunks = [&](int it) { return (g.units + kBlock * it - 1) / (kBlock * it); };
+    while (iters > 2 && (long long)B * chunks(iters) < 2048) iters = iters > 5 ? iters / 2 : iters - 1;
+    g.units_per_block = kBlock * iters;
+    g.nchunks = chunks(iters);
+    return g;
+}
+}  // namespace gclm
+
+extern "C" {
+
+int gclm_version(void) { return GCLM_VERSION; }
+
+int gclm_default_config(gclm_config* cfg) {
+    if (!cfg) return -1;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->camera_model = GCLM_PINHOLE;
+    cfg->num_steps = 30;
+    cfg->lambda0 = 0.1f;
+    cfg->early_stop = 1;
+    cfg->atol = 1e-8f;
+    cfg->rtol = 1e-8f;
+    cfg->use_spherical_manifold = 1;
+    cfg->use_log_focal = 1;
+    cfg->up_loss_fn_scale = 1e-2f;
+    cfg->lat_loss_fn_scale = 1e-2f;
+    cfg->estimate_gravity = cfg->estimate_focal = cfg->estimate_dist = 1;
+    cfg->compute_uncertainty = 1;
+    return 0;
+}
+
+int gclm_create(gclm_handle** out, const gclm_config* cfg, int device) {
+    if (!out || !cfg) return fail(nullptr, -1, "gclm_create: null argument");
+    *out = nullptr;
+    if (const char* msg = validate(*cfg)) return fail(nullptr, -2, "gclm_create: %s", msg);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, -11, "gclm_create: no HIP device visible (the HIP path has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(nullptr, -2, "gclm_create: device %d out of range (%d devices)", device, ndev);
+    gclm_handle* h = new (std::nothrow) gclm_handle();
+    if (!h) return fail(nullptr, -12, "gclm_create: out of host memory");
+    h->cfg = *cfg;
+    h->device = device;
+    *out = h;
+    return 0;
+}
+
+int gclm_configure(gclm_handle* h, const gclm_config* cfg) {
+    if (!h || !cfg) return -1;
+    if (const char* msg = validate(*cfg)) return fail(h, -2, "gclm_configure: %s", msg);
+    h->cfg = *cfg;
+    h->sh.active = false;
+    return 0;
+}
+
+int gclm_destroy(gclm_handle* h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    if (h->ws) (void)hipFree(h->ws);
+    delete h;
+    return 0;
+}
+
+const char* gclm_last_error(const gclm_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+size_t gclm_workspace_bytes(const gclm_handle* h) { return h ? h->ws_bytes : 0; }
+
+int gclm_set_timing(gclm_handle* h, int enabled) {
+    if (!h) return -1;
+    h->timing = enabled != 0;
+    h->ev_used = 0;
+    return 0;
+}
+
+int gclm_last_pass_timing(gclm_handle* h, int* n_launches, float* total_ms) {
+    if (!h) return -1;
+    if (!h->timing) return fail(h, -4, "timing not enabled");
+    float tot = 0.f;
+    for (int i = 0; i + 1 < h->ev_used; i += 2) {
+        GCLM_HIP(h, hipEventSynchronize(h->ev[i + 1]));
+        float ms = 0.f;
+        GCLM_HIP(h, hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+        tot += ms;
+    }
+    if (n_launches) *n_launches = h->ev_used / 2;
+    if (total_ms) *total_ms = tot;
+    return 0;
+}
+
+int gclm_solve(gclm_handle* h, const float* d_up, const float* d_lat, const float* d_up_conf,
+               const float* d_lat_conf, int B, int H, int W, float* d_cam_io, float* d_grav_io,
+               float* d_info_out, void* stream) {
+    if (!h) return -1;
+    if (int rc = check_shapes(h, d_lat, B, H, W)) return rc;
+    if (!d_cam_io || !d_grav_io || !d_info_out) return fail(h, -3, "gclm_solve: null output pointer");
+    if (B == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GCLM_HIP(h, hipSetDevice(h->device));
+    const bool al = is_aligned16(d_up) && is_aligned16(d_lat) && is_aligned16(d_up_conf) && is_aligned16(d_lat_conf);
+    const Geometry geo = plan_geometry(B, H, W, al);
+    SolveCtx& c = h->ctx;
+    c.cfg = h->cfg;
+    c.B = B; c.H = H; c.W = W; c.nchunks = geo.nchunks;
+    if (int rc = setup_groups(h, B)) return rc;
+    if (int rc = ensure_workspace(h, B, geo.nchunks, c.n_groups)) return rc;
+    h->ev_used = 0;
+    h->sh.active = false;
+
+    GCLM_HIP(h, hipMemsetAsync(d_info_out, 0, sizeof(float) * GCLM_INFO_STRIDE * (size_t)B, s));
+    GCLM_HIP(h, launch_init(c, d_cam_io, d_grav_io, s));
+    const bool es = h->cfg.early_stop != 0;
+    for (int step = 0; step < h->cfg.num_steps; ++step) {
+        const SweepArgs a = sweep_args(h, d_up, d_lat, d_up_conf, d_lat_conf, c.pb[step & 1], geo, es);
+        if (int rc = timed_sweep(h, a, s)) return rc;
+        if (!h->cfg.shared_intrinsics) {
+            GCLM_HIP(h, launch_update(c, step, s));
+        } else {
+            GCLM_HIP(h, launch_shared_reduce(c, step, h->group_partials, s));
+            GCLM_HIP(h, launch_shared_apply(c, step, h->group_partials, s));
+        }
+        if (es) GCLM_HIP(h, launch_decide(c, step, s));
+    }
+    GCLM_HIP(h, launch_prep_final(c, s));
+    const SweepArgs a = sweep_args(h, d_up, d_lat, d_up_conf, d_lat_conf, c.pb_final, geo, false);
+    if (int rc = timed_sweep(h, a, s)) return rc;
+    GCLM_HIP(h, launch_finalize(c, d_cam_io, d_grav_io, d_info_out, s));
+    return 0;
+}
+
+int gclm_system(gclm_handle* h, const float* d_up, const float* d_lat, const float* d_up_conf,
+                const float* d_lat_conf, int B, int H, int W, const float* d_cam, const float* d_grav,
+                int as_rpf, float* d_cost, float* d_grad, float* d_hess, void* stream) {
+    if (!h) return -1;
+    if (int rc = check_shapes(h, d_lat, B, H, W)) return rc;
+    if (!d_cam || !d_grav || !d_cost || !d_grad || !d_hess) return fail(h, -3, "gclm_system: null pointer");
+    if (B == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GCLM_HIP(h, hipSetDevice(h->device));
+    const bool al = is_aligned16(d_up) && is_aligned16(d_lat) && is_aligned16(d_up_conf) && is_aligned16(d_lat_conf);
+    const Geometry geo = plan_geometry(B, H, W, al);
+    SolveCtx& c = h->ctx;
+    c.cfg = h->cfg;
+    c.B = B; c.H = H; c.W = W; c.nchunks = geo.nchunks;
+    c.n_groups = 0; c.group_size = 1; c.group_of_frame = nullptr;
+    if (int rc = ensure_workspace(h, B, geo.nchunks, 0)) return rc;
+    h->sh.active = false;
+    GCLM_HIP(h, launch_pblock_from_params(c, d_cam, d_grav, as_rpf, c.pb_final, s));
+    const SweepArgs a = sweep_args(h, d_up, d_lat, d_up_conf, d_lat_conf, c.pb_final, geo, false);
+    GCLM_HIP(h, launch_sweep(h->cfg.camera_model, a, s));
+    GCLM_HIP(h, launch_system_out(c, d_cost, d_grad, d_hess, s));
+    return 0;
+}
+
+int gclm_shared_begin(gclm_handle* h, const float* d_up, const float* d_lat, const float* d_up_conf,
+                      const float* d_lat_conf, int B_local, int H, int W, float* d_cam_io,
+                      float* d_grav_io, const int32_t* d_group_of_frame, int num_groups, void* stream) {
+    if (!h) return -1;
+    if (!h->cfg.shared_intrinsics) return fail(h, -2, "gclm_shared_begin: handle is not configured for shared_intrinsics");
+    if (h->cfg.early_stop) return fail(h, -2, "gclm_shared_begin: early_stop needs a global decision; run with early_stop=0");
+    if (int rc = check_shapes(h, d_lat, B_local, H, W)) return rc;
+    if (!d_cam_io || !d_grav_io || !d_group_of_frame || num_groups <= 0) return fail(h, -3, "gclm_shared_begin: bad arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GCLM_HIP(h, hipSetDevice(h->device));
+    const bool al = is_aligned16(d_up) && is_aligned16(d_lat) && is_aligned16(d_up_conf) && is_aligned16(d_lat_conf);
+    const int Bp = B_local > 0 ? B_local : 1;
+    h->sh.geo = plan_geometry(Bp, H, W, al);
+    SolveCtx& c = h->ctx;
+    c.cfg = h->cfg;
+    c.B = B_local; c.H = H; c.W = W; c.nchunks = h->sh.geo.nchunks;
+    c.n_groups = num_groups; c.group_size = 1; c.group_of_frame = d_group_of_frame;
+    if (int rc = ensure_workspace(h, Bp, h->sh.geo.nchunks, num_groups)) return rc;
+    h->sh.up = d_up; h->sh.lat = d_lat; h->sh.upc = d_up_conf; h->sh.latc = d_lat_conf;
+    h->sh.cam_io = d_cam_io; h->sh.grav_io = d_grav_io;
+    h->sh.active = true;
+    h->ev_used = 0;
+    GCLM_HIP(h, launch_init(c, d_cam_io, d_grav_io, s));
+    return 0;
+}
+
+int gclm_shared_reduce(gclm_handle* h, int step, float* d_partials, void* stream) {
+    if (!h) return -1;
+    if (!h->sh.active) return fail(h, -4, "gclm_shared_reduce: no active session (call gclm_shared_begin)");
+    if (!d_partials || step < 0 || step >= h->cfg.num_steps) return fail(h, -3, "gclm_shared_reduce: bad arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GCLM_HIP(h, hipSetDevice(h->device));
+    SolveCtx& c = h->ctx;
+    if (c.B > 0) {
+        const SweepArgs a = sweep_args(h, h->sh.up, h->sh.lat, h->sh.upc, h->sh.latc, c.pb[step & 1], h->sh.geo, false);
+        if (int rc = timed_sweep(h, a, s)) return rc;
+    }
+    GCLM_HIP(h, launch_shared_reduce(c, step, d_partials, s));
+    return 0;
+}
+
+int gclm_shared_apply(gclm_handle* h, int step, const float* d_partials, void* stream) {
+    if (!h) return -1;
+    if (!h->sh.active) return fail(h, -4, "gclm_shared_apply: no active session");
+    if (!d_partials || step < 0 || step >= h->cfg.num_steps) return fail(h, -3, "gclm_shared_apply: bad arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GCLM_HIP(h, hipSetDevice(h->device));
+    if (h->ctx.B > 0) GCLM_HIP(h, launch_shared_apply(h->ctx, step, d_partials, s));
+    return 0;
+}
+
+int gclm_shared_finish(gclm_handle* h, float* d_info_out, void* stream) {
+    if (!h) return -1;
+    if (!h->sh.active) return fail(h, -4, "gclm_shared_finish: no active session");
+    if (!d_info_out) return fail(h, -3, "gclm_shared_finish: null info pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GCLM_HIP(h, hipSetDevice(h->device));
+    SolveCtx& c = h->ctx;
+    h->sh.active = false;
+    if (c.B == 0) return 0;
+    GCLM_HIP(h, hipMemsetAsync(d_info_out, 0, sizeof(float) * GCLM_INFO_STRIDE * (size_t)c.B, s));
+    GCLM_HIP(h, launch_prep_final(c, s));
+    const SweepArgs a = sweep_args(h, h->sh.up, h->sh.lat, h->sh.upc, h->sh.latc, c.pb_final, h->sh.geo, false);
+    if (int rc = timed_sweep(h, a, s)) return rc;
+    GCLM_HIP(h, launch_finalize(c, h->sh.cam_io, h->sh.grav_io, d_info_out, s));
+    return 0;
+}
+
+int gclm_synth_fields(int camera_model, uint64_t seed, int64_t first_index, int B, int H, int W,
+                      float noise_sigma, float* d_up, float* d_lat, float* d_up_conf,
+                      float* d_lat_conf, float* d_gt_cam, float* d_gt_grav, void* stream) {
+    if (!d_up || !d_lat || B < 0 || H <= 0 || W <= 0) return -3;
+    if (camera_model != GCLM_PINHOLE && camera_model != GCLM_SIMPLE_RADIAL) return -2;
+    hipError_t e = launch_synth(camera_model, seed, first_index, B, H, W, noise_sigma, d_up, d_lat, d_up_conf,
+                                d_lat_conf, d_gt_cam, d_gt_grav, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : -10;
+}
+
+}  // extern "C"

@@ -1,0 +1,98 @@
+// gclm_internal.h -- shared declarations of the three translation units of libgeocalib_hip.so
+// (gclm_pass.hip: per-pixel sweep, gclm_update.hip: per-image / per-group solve + update,
+//  gclm_api.hip: C ABI and launch sequence).  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gclm.h"
+
+namespace gclm {
+
+constexpr int kBlock = 256;        // 4 waves of 64
+constexpr int kNAcc = 16;          // floats per partial record (see enum Acc)
+constexpr int kPBlockFloats = 16;
+constexpr int kStateFloats = 16;
+
+// Partial / accumulator record of one sweep over (part of) an image.
+//   [0] sum Huber cost up   [1] sum Huber cost latitude
+//   [2..5] G = sum w J^T r over columns (d1, d2, f, k1)
+//   [6..15] upper triangle of sum w J^T J: 00 01 02 03 11 12 13 22 23 33
+enum Acc { A_CU = 0, A_CL = 1, A_G0 = 2, A_H00 = 6 };
+
+// Per-image constants consumed by the sweep (written by the update kernels).
+struct __attribute__((aligned(16))) PBlock {
+    float ifx, ify, cx, cy;          // normalize(): u = (x - cx) * ifx          camera.py:309-311
+    float ga, gb, gc, k1;            // gravity (a,b,c), distortion
+    float T00, T01, T10, T11;        // tangent basis T[i][k] (3x2): SphericalManifold.J_plus(g) in the
+    float T20, T21, wfx, wfy;        //   loop, Gravity.J_rp() for uncertainty; (wfx,wfy): focal column
+};                                   //   scale (1,1) for log-focal, (1/fx,1/fy) otherwise
+static_assert(sizeof(PBlock) == kPBlockFloats * 4, "PBlock layout");
+
+// Per-image optimiser state (double-buffered across steps).
+struct __attribute__((aligned(16))) State {
+    float w, h, fx, fy, cx, cy, k1, k2;   // BaseCamera._data layout
+    float gx, gy, gz;                      // Gravity._data
+    float lambda, prev_cost, fails, init_cu, init_cl;   // init_*: initial mean costs (infos)
+};
+static_assert(sizeof(State) == kStateFloats * 4, "State layout");
+
+// Device-side control block: batch-global early stop without host synchronisation.
+struct Ctrl {
+    int stopped;                           // set once every image's cost is "close" (early_stop)
+    int final_sel;                         // state buffer (0/1) that holds the final estimate
+    int pad[2];
+    int notclose[GCLM_MAX_STEPS + 4];      // per step: number of images whose cost still moved
+};
+
+struct SweepArgs {
+    const float* up;        // (B,2,H,W) or nullptr
+    const float* lat;       // (B,1,H,W)
+    const float* upc;       // (B,H,W) or nullptr
+    const float* latc;      // (B,H,W) or nullptr
+    const PBlock* pb;       // (B)
+    const Ctrl* ctrl;       // nullptr: never skip
+    float* partials;        // (B, nchunks, kNAcc)
+    int B, H, W;
+    int nchunks;            // blocks per image
+    int units_per_block;    // float4 groups (or pixels in the scalar path) per block
+    int vec;                // 4: float4 path, 1: scalar path
+    int skip_if_stopped;    // loop sweeps return immediately once ctrl->stopped is set
+    float up_scale, lat_scale;   // Huber scales a (lm_optimizer.py:158-159)
+};
+
+struct Geometry {          // how a sweep is cut into blocks
+    int vec, units, nchunks, units_per_block;
+};
+Geometry plan_geometry(int B, int H, int W, bool aligned16);
+
+// gclm_pass.hip
+hipError_t launch_sweep(int camera_model, const SweepArgs& a, hipStream_t s);
+
+// gclm_update.hip
+struct SolveCtx {
+    gclm_config cfg;
+    int B, H, W, nchunks;
+    int n_groups, group_size;   // shared intrinsics
+    const int32_t* group_of_frame; // device (B), non-decreasing group id per frame, or nullptr (uniform group_size)
+    State* state[2];
+    PBlock* pb[2];
+    PBlock* pb_final;
+    float* partials;
+    float* frame_sys;           // (B, kNAcc) reduced per-frame system (shared mode / system())
+    Ctrl* ctrl;
+};
+hipError_t launch_init(const SolveCtx& c, const float* d_cam, const float* d_grav, hipStream_t s);
+hipError_t launch_update(const SolveCtx& c, int step, hipStream_t s);
+hipError_t launch_decide(const SolveCtx& c, int step, hipStream_t s);
+hipError_t launch_prep_final(const SolveCtx& c, hipStream_t s);
+hipError_t launch_finalize(const SolveCtx& c, float* d_cam, float* d_grav, float* d_info, hipStream_t s);
+hipError_t launch_shared_reduce(const SolveCtx& c, int step, float* d_group_partials, hipStream_t s);
+hipError_t launch_shared_apply(const SolveCtx& c, int step, const float* d_group_partials, hipStream_t s);
+hipError_t launch_system_out(const SolveCtx& c, float* d_cost, float* d_grad, float* d_hess, hipStream_t s);
+hipError_t launch_pblock_from_params(const SolveCtx& c, const float* d_cam, const float* d_grav, int as_rpf, PBlock* out, hipStream_t s);
+hipError_t launch_synth(int camera_model, uint64_t seed, int64_t first_index, int B, int H, int W,
+                        float sigma, float* up, float* lat, float* upc, float* latc, float* gt_cam,
+                        float* gt_grav, hipStream_t s);
+
+}  // namespace gclm

@@ -1,0 +1,255 @@
+"""Levenberg-Marquardt calibration on MI355X: host side of the HIP path.
+
+Drop-in for the reference's `geocalib.lm_optimizer.LMOptimizer` (lm_optimizer.py:141-664): same
+constructor conf keys (`default_conf`), `set_camera_model`, `.shared_intrinsics`, `.num_steps`,
+`.training`, dict-in / dict-out `forward`.  The whole optimisation (residuals, Huber weights,
+analytic Jacobians, J^T W J / J^T W r, damped Cholesky, manifold update, lambda rule, early stop,
+uncertainty) runs in hand-written HIP kernels behind the C ABI of include/gclm.h; this module
+only prepares the initial estimate, the configuration and the output dict.  torch is used for
+device memory and the stream, nothing else.  There is NO CPU fallback: CPU tensors or a missing
+libgeocalib_hip.so raise.
+"""
+import logging
+from types import SimpleNamespace
+from typing import Any, Dict, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .camera import BaseCamera, camera_models
+from .gravity import Gravity
+from .utils import focal2fov
+
+logger = logging.getLogger(__name__)
+
+_HIP_MODELS = ("pinhole", "simple_radial")
+
+
+def get_trivial_estimation(data: Dict[str, torch.Tensor], camera_model) -> Tuple[BaseCamera, Gravity]:
+    """Initial estimate: roll = pitch = 0, f = 0.7 max(h, w) through a vfov round trip, principal
+    point at the centre, priors substituted where given (reference: lm_optimizer.py:20-58).
+    Like the reference this needs `latitude_field` to be present."""
+    ref = data.get("up_field", data["latitude_field"]).detach()
+    B, (h, w) = ref.shape[0], ref.shape[-2:]
+    hs, ws = ref.new_ones((B,)) * h, ref.new_ones((B,)) * w
+    focal = data.get("prior_focal", 0.7 * torch.max(hs, ws))
+    params = {"width": ws, "height": hs, "vfov": focal2fov(focal, h)}
+    if "scales" in data:
+        params["scales"] = data["scales"]
+    if "prior_dist" in data:
+        params["dist"] = data["prior_dist"]
+    camera = camera_model.from_dict(params).float().to(ref.device)
+    gravity = Gravity.from_rp(ref.new_zeros((B,)), ref.new_zeros((B,))).float().to(ref.device)
+    if "prior_gravity" in data:
+        g = data["prior_gravity"].float().to(ref.device)
+        gravity = Gravity(g) if isinstance(g, torch.Tensor) else g
+    return camera, gravity
+
+
+class _Handle:
+    """Owns one gclm_handle (per device)."""
+
+    def __init__(self, cfg: _lib.GclmConfig, device: torch.device):
+        lib = _lib.load()
+        self.ptr = _lib.C.c_void_p()
+        rc = lib.gclm_create(_lib.C.byref(self.ptr), _lib.C.byref(cfg), device.index or 0)
+        _lib.check(rc, None, "gclm_create")
+        self.key = cfg.key()
+
+    def configure(self, cfg: _lib.GclmConfig):
+        if cfg.key() != self.key:
+            _lib.check(_lib.load().gclm_configure(self.ptr, _lib.C.byref(cfg)), self.ptr, "gclm_configure")
+            self.key = cfg.key()
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _lib.load().gclm_destroy(self.ptr)
+        except Exception:
+            pass
+
+
+def _dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"geocalib_amd: `{name}` must live on a HIP device (got {t.device}); "
+                           "the MI355X path has no CPU fallback")
+    return t.detach().to(torch.float32).contiguous()
+
+
+class LMOptimizer(nn.Module):
+    """Batched LM optimiser for camera calibration (HIP / gfx950)."""
+
+    default_conf = {
+        "camera_model": "pinhole",
+        "shared_intrinsics": False,
+        "num_steps": 30,
+        "lambda_": 0.1,
+        "fix_lambda": False,
+        "early_stop": True,
+        "atol": 1e-8,
+        "rtol": 1e-8,
+        "use_spherical_manifold": True,
+        "use_log_focal": True,
+        "up_loss_fn_scale": 1e-2,
+        "lat_loss_fn_scale": 1e-2,
+        "verbose": False,
+        # extension: frames per shared-intrinsics group (None = the whole batch is one group,
+        # which is the reference's only mode; lm_optimizer.py:350-383)
+        "group_size": None,
+    }
+
+    def __init__(self, conf: Dict[str, Any] = None):
+        super().__init__()
+        conf = conf or {}
+        unknown = set(conf) - set(self.default_conf)
+        if unknown:
+            logger.debug("ignoring unknown conf keys: %s", sorted(unknown))
+        self.conf = conf = SimpleNamespace(**{**self.default_conf, **conf})
+        self.num_steps = conf.num_steps
+        self.set_camera_model(conf.camera_model)
+        self.setup_optimization_and_priors(shared_intrinsics=conf.shared_intrinsics)
+        self._handles: Dict[int, _Handle] = {}
+
+    # ------------------------------------------------------------------ reference API
+    def set_camera_model(self, camera_model: str) -> None:
+        assert camera_model in camera_models, f"Unknown camera model: {camera_model} not in {camera_models.keys()}"
+        self.camera_model = camera_models[camera_model]
+        self.camera_has_distortion = hasattr(self.camera_model, "dist")
+
+    def setup_optimization_and_priors(self, data: Dict[str, torch.Tensor] = None,
+                                      shared_intrinsics: bool = False) -> None:
+        """Which parameters are free given the priors in `data` (reference: lm_optimizer.py:189-246)."""
+        data = data or {}
+        self.shared_intrinsics = shared_intrinsics
+        self.estimate_gravity = "prior_gravity" not in data
+        self.estimate_focal = "prior_focal" not in data
+        self.estimate_dist = self.camera_has_distortion and "prior_dist" not in data
+        self.gravity_delta_dims = (0, 1) if self.estimate_gravity else (-1,)
+        self.focal_delta_dims = (max(self.gravity_delta_dims) + 1,) if self.estimate_focal else (-1,)
+        self.dist_delta_dims = None
+        if self.estimate_dist:
+            first = self.focal_delta_dims[-1] + 1
+            self.dist_delta_dims = tuple(range(first, first + self.camera_model.num_dist_params()))
+        self.n_intrinsic_params = self.estimate_focal + (
+            self.camera_model.num_dist_params() if self.camera_has_distortion else 0)
+
+    # ------------------------------------------------------------------ C-ABI plumbing
+    def _config(self) -> _lib.GclmConfig:
+        c = self.conf
+        name = self.camera_model.name()
+        if name not in _HIP_MODELS:
+            raise NotImplementedError(f"camera model `{name}` is not implemented by the HIP path yet "
+                                      f"(available: {_HIP_MODELS})")
+        cfg = _lib.GclmConfig()
+        cfg.camera_model = _lib.CAMERA_MODEL_IDS[name]
+        cfg.shared_intrinsics = int(bool(self.shared_intrinsics))
+        cfg.group_size = int(c.group_size or 0)
+        cfg.num_steps = int(self.num_steps)
+        cfg.lambda0 = float(c.lambda_)
+        cfg.fix_lambda = int(bool(c.fix_lambda))
+        cfg.early_stop = int(bool(c.early_stop))
+        cfg.atol, cfg.rtol = float(c.atol), float(c.rtol)
+        cfg.use_spherical_manifold = int(bool(c.use_spherical_manifold))
+        cfg.use_log_focal = int(bool(c.use_log_focal))
+        cfg.up_loss_fn_scale = float(c.up_loss_fn_scale)
+        cfg.lat_loss_fn_scale = float(c.lat_loss_fn_scale)
+        cfg.estimate_gravity = int(self.estimate_gravity)
+        cfg.estimate_focal = int(self.estimate_focal)
+        cfg.estimate_dist = int(self.estimate_dist)
+        cfg.compute_uncertainty = int(not self.training)
+        return cfg
+
+    def _handle(self, device: torch.device) -> _Handle:
+        cfg = self._config()
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        h = self._handles.get(idx)
+        if h is None:
+            h = self._handles[idx] = _Handle(cfg, torch.device("cuda", idx))
+        else:
+            h.configure(cfg)
+        return h
+
+    @staticmethod
+    def _ptr(t):
+        return None if t is None else t.data_ptr()
+
+    def _fields(self, data):
+        lat = _dev_f32(data["latitude_field"], "latitude_field")
+        up = _dev_f32(data["up_field"], "up_field") if "up_field" in data else None
+        upc = _dev_f32(data["up_confidence"], "up_confidence") if "up_confidence" in data and up is not None else None
+        latc = _dev_f32(data["latitude_confidence"], "latitude_confidence") if "latitude_confidence" in data else None
+        B, _, H, W = lat.shape
+        if up is not None:
+            assert up.shape == (B, 2, H, W), up.shape
+        for c in (upc, latc):
+            assert c is None or c.numel() == B * H * W, c.shape
+        return up, lat, upc, latc, (B, H, W)
+
+    def optimize(self, data: Dict[str, torch.Tensor], camera_opt: BaseCamera,
+                 gravity_opt: Gravity) -> Tuple[BaseCamera, Gravity, Dict[str, torch.Tensor]]:
+        """All LM steps + final costs + uncertainty on the device (reference: lm_optimizer.py:551-644)."""
+        up, lat, upc, latc, (B, H, W) = self._fields(data)
+        device = lat.device
+        h = self._handle(device)
+        cam = _dev_f32(camera_opt._data, "camera").clone()
+        grav = _dev_f32(gravity_opt._data, "gravity").clone()
+        info = torch.empty((B, _lib.INFO_STRIDE), dtype=torch.float32, device=device)
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            rc = _lib.load().gclm_solve(h.ptr, self._ptr(up), self._ptr(lat), self._ptr(upc), self._ptr(latc),
+                                        B, H, W, cam.data_ptr(), grav.data_ptr(), info.data_ptr(), stream)
+        _lib.check(rc, h.ptr, "gclm_solve")
+        return camera_opt.__class__(cam), Gravity(grav), self._unpack_info(info, up is not None)
+
+    def _unpack_info(self, info: torch.Tensor, has_up: bool) -> Dict[str, torch.Tensor]:
+        I = _lib.INFO
+        out = {"stop_at": info[:, I["stop_at"]]}
+        if has_up:
+            out["initial_up_cost"] = info[:, I["initial_up_cost"]]
+        out["initial_latitude_cost"] = info[:, I["initial_latitude_cost"]]
+        out["initial_cost"] = info[:, I["initial_cost"]]
+        if not self.training:
+            P = (2 * self.estimate_gravity + self.estimate_focal
+                 + (self.camera_model.num_dist_params() if self.camera_has_distortion else 0))
+            c0 = I["covariance"]
+            out["covariance"] = info[:, c0:c0 + P * P].reshape(-1, P, P)
+            for k in ("roll_uncertainty", "pitch_uncertainty", "gravity_uncertainty", "focal_uncertainty",
+                      "vfov_uncertainty"):
+                out[k] = info[:, I[k]]
+        if has_up:
+            out["final_up_cost"] = info[:, I["final_up_cost"]]
+        out["final_latitude_cost"] = info[:, I["final_latitude_cost"]]
+        out["final_cost"] = info[:, I["final_cost"]]
+        out["step_failures"] = info[:, I["step_failures"]]
+        return out
+
+    def forward(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """Run the LM optimisation (reference: lm_optimizer.py:646-664)."""
+        with torch.no_grad():
+            camera_init, gravity_init = get_trivial_estimation(data, self.camera_model)
+            self.setup_optimization_and_priors(data, shared_intrinsics=self.shared_intrinsics)
+            camera_opt, gravity_opt, infos = self.optimize(data, camera_init, gravity_init)
+        return {"camera": camera_opt, "gravity": gravity_opt, **infos}
+
+    # ------------------------------------------------------------------ kernel-level entry (tests, tools)
+    def system(self, data: Dict[str, torch.Tensor], camera: BaseCamera, gravity: Gravity,
+               as_rpf: bool = False) -> Dict[str, torch.Tensor]:
+        """One fused sweep at fixed parameters: mean costs, J^T W r (B,P_full) and J^T W J
+        (reference: calculate_residuals + calculate_costs + setup_system, lm_optimizer.py:248-461)."""
+        up, lat, upc, latc, (B, H, W) = self._fields(data)
+        device = lat.device
+        h = self._handle(device)
+        cam = _dev_f32(camera._data, "camera")
+        grav = _dev_f32(gravity._data, "gravity")
+        cost = torch.empty((B, 2), dtype=torch.float32, device=device)
+        grad = torch.empty((B, _lib.MAX_PARAMS), dtype=torch.float32, device=device)
+        hess = torch.empty((B, _lib.MAX_PARAMS, _lib.MAX_PARAMS), dtype=torch.float32, device=device)
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            rc = _lib.load().gclm_system(h.ptr, self._ptr(up), self._ptr(lat), self._ptr(upc), self._ptr(latc),
+                                         B, H, W, cam.data_ptr(), grav.data_ptr(), int(as_rpf),
+                                         cost.data_ptr(), grad.data_ptr(), hess.data_ptr(), stream)
+        _lib.check(rc, h.ptr, "gclm_system")
+        P = 3 + (self.camera_model.num_dist_params() if self.camera_has_distortion else 0)
+        return {"cost_up": cost[:, 0], "cost_lat": cost[:, 1], "G": grad[:, :P], "H": hess[:, :P, :P]}

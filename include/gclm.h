@@ -1,0 +1,166 @@
+/*
+ * gclm.h -- C ABI of libgeocalib_hip.so: GeoCalib's batched Levenberg-Marquardt calibration
+ * (perspective-field residuals, analytic Jacobians, J^T W J / J^T W r reductions, damped solve,
+ * manifold update) as hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * The reference (cvg/GeoCalib) has no native/FFI boundary: its seam is the Python attribute
+ * `GeoCalib.optimizer` (geocalib/geocalib.py:106,119), an `LMOptimizer` (geocalib/lm_optimizer.py:141).
+ * Every entry point below states which reference function(s) it replaces.  All pointers named
+ * `d_*` are DEVICE pointers owned by the caller (torch-ROCm tensors); `stream` is a hipStream_t
+ * passed as void*.  Calls are asynchronous on `stream` and never synchronise the device.
+ * Return value: 0 = ok, negative = error (message via gclm_last_error).  No C++ exception crosses
+ * this boundary.  A handle is not thread-safe: one handle per (device, stream).
+ * Numerical failure (non positive-definite system) is NOT an error: the image takes a zero step,
+ * like lm_optimizer.py:129-133 (there batch-global, here per image / per shared group).
+ */
+#ifndef GCLM_H
+#define GCLM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GCLM_VERSION 100
+
+/* camera_models of geocalib/camera.py:945-950 */
+enum gclm_camera_model {
+    GCLM_PINHOLE = 0,           /* camera.py:522 */
+    GCLM_SIMPLE_RADIAL = 1,     /* camera.py:565 */
+    GCLM_RADIAL = 2,            /* camera.py:663 */
+    GCLM_SIMPLE_DIVISIONAL = 3  /* camera.py:789 */
+};
+
+#define GCLM_MAX_PARAMS 5     /* delta_g1, delta_g2, focal, k1, k2 */
+#define GCLM_MAX_STEPS 256
+#define GCLM_CAM_STRIDE 8     /* {w,h,fx,fy,cx,cy,k1,k2}: BaseCamera._data, camera.py:25-41 */
+#define GCLM_GRAV_STRIDE 3    /* unit gravity: Gravity._data, gravity.py:18-28 */
+
+/* info_out row layout (floats) -- the `infos` dict of lm_optimizer.py:575,586-588,509-516,638-642 */
+#define GCLM_INFO_STRIDE 48
+enum gclm_info_slot {
+    GCLM_INFO_STOP_AT = 0,
+    GCLM_INFO_INITIAL_UP_COST = 1,
+    GCLM_INFO_INITIAL_LAT_COST = 2,
+    GCLM_INFO_INITIAL_COST = 3,
+    GCLM_INFO_FINAL_UP_COST = 4,
+    GCLM_INFO_FINAL_LAT_COST = 5,
+    GCLM_INFO_FINAL_COST = 6,
+    GCLM_INFO_ROLL_UNC = 7,
+    GCLM_INFO_PITCH_UNC = 8,
+    GCLM_INFO_GRAVITY_UNC = 9,
+    GCLM_INFO_FOCAL_UNC = 10,
+    GCLM_INFO_VFOV_UNC = 11,
+    GCLM_INFO_NPARAMS = 12,
+    GCLM_INFO_LAMBDA = 13,
+    GCLM_INFO_STEP_FAILURES = 14,  /* number of LM steps whose Cholesky failed (zero step) */
+    GCLM_INFO_COV = 16             /* covariance, P x P row-major, up to 25 floats */
+};
+
+/*
+ * Mirrors LMOptimizer.default_conf (lm_optimizer.py:144-162) plus what
+ * setup_optimization_and_priors (lm_optimizer.py:189-246) derives from the priors.
+ */
+typedef struct gclm_config {
+    int32_t camera_model;            /* enum gclm_camera_model */
+    int32_t shared_intrinsics;       /* lm_optimizer.py:147; groups of `group_size` frames */
+    int32_t group_size;              /* frames per shared-intrinsics group; 0 = whole batch (reference) */
+    int32_t num_steps;               /* :149 */
+    float lambda0;                   /* :150 */
+    int32_t fix_lambda;              /* :151 */
+    int32_t early_stop;              /* :152 (batch-global, :90-92,:619-625) */
+    float atol, rtol;                /* :153-154 */
+    int32_t use_spherical_manifold;  /* :155 */
+    int32_t use_log_focal;           /* :156 */
+    float up_loss_fn_scale;          /* :158 */
+    float lat_loss_fn_scale;         /* :159 */
+    int32_t estimate_gravity;        /* :204-207 (0 when prior_gravity is given) */
+    int32_t estimate_focal;          /* :209-212 */
+    int32_t estimate_dist;           /* :214-221 */
+    int32_t compute_uncertainty;     /* eval mode: estimate_uncertainty (:635-636) */
+} gclm_config;
+
+typedef struct gclm_handle gclm_handle;
+
+/* Library / ABI version (GCLM_VERSION of the build). */
+int gclm_version(void);
+
+/* Fill `cfg` with LMOptimizer.default_conf (lm_optimizer.py:144-162), everything estimated, eval mode. */
+int gclm_default_config(gclm_config* cfg);
+
+/* LMOptimizer.__init__ (lm_optimizer.py:164-171): validate the configuration, bind to `device`. */
+int gclm_create(gclm_handle** out, const gclm_config* cfg, int device);
+
+/* Re-configure (set_camera_model :173, .shared_intrinsics, priors) without dropping the workspace. */
+int gclm_configure(gclm_handle* h, const gclm_config* cfg);
+
+int gclm_destroy(gclm_handle* h);
+
+/* Message of the last failing call on this handle (or of the last failing gclm_create if h == NULL). */
+const char* gclm_last_error(const gclm_handle* h);
+
+/* Bytes of device scratch the handle holds (grows on demand in gclm_solve, never per call after warm-up). */
+size_t gclm_workspace_bytes(const gclm_handle* h);
+
+/*
+ * LMOptimizer.optimize (lm_optimizer.py:551-644) for B images of H x W pixels: all LM steps,
+ * the final costs and (compute_uncertainty) estimate_uncertainty (:463-516).
+ *   d_up        (B,2,H,W) float32 up field, or NULL          (data["up_field"])
+ *   d_lat       (B,1,H,W) float32 latitude in radians        (data["latitude_field"], required like :31)
+ *   d_up_conf   (B,H,W)   float32 or NULL                    (data["up_confidence"])
+ *   d_lat_conf  (B,H,W)   float32 or NULL                    (data["latitude_confidence"])
+ *   d_cam_io    (B,8)     in: initial camera (get_trivial_estimation :20-58), out: optimised camera
+ *   d_grav_io   (B,3)     in: initial unit gravity, out: optimised gravity
+ *   d_info_out  (B,GCLM_INFO_STRIDE) float32, see enum gclm_info_slot
+ */
+int gclm_solve(gclm_handle* h, const float* d_up, const float* d_lat, const float* d_up_conf,
+               const float* d_lat_conf, int B, int H, int W, float* d_cam_io, float* d_grav_io,
+               float* d_info_out, void* stream);
+
+/*
+ * One fused sweep at fixed parameters: calculate_residuals + calculate_costs + setup_system
+ * (lm_optimizer.py:248-315,387-461).  as_rpf selects the (roll, pitch, focal) parametrisation used
+ * by estimate_uncertainty (:481-483).  Outputs, per image: d_cost (B,2) mean up / latitude Huber cost,
+ * d_grad (B,5) and d_hess (B,5,5) over the full column set [d1,d2,f,k1,k2] (unused columns zero).
+ */
+int gclm_system(gclm_handle* h, const float* d_up, const float* d_lat, const float* d_up_conf,
+                const float* d_lat_conf, int B, int H, int W, const float* d_cam, const float* d_grav,
+                int as_rpf, float* d_cost, float* d_grad, float* d_hess, void* stream);
+
+/*
+ * Shared-intrinsics solve with a group's frames split over several devices (BASELINE config 5).
+ * The caller drives the LM loop: per step, gclm_shared_reduce leaves, for each of the G groups,
+ * the local Schur partials [sum E^T D^-1 E (ni x ni) | sum E^T D^-1 g (ni) | sum H_ii (ni x ni) | sum g_i (ni)]
+ * in d_partials (G x GCLM_SHARED_PARTIAL_STRIDE floats); the caller all-reduces (sum) that buffer over the
+ * ranks holding frames of the same groups (RCCL), then gclm_shared_apply solves and updates its frames.
+ * Together they replace the dense arrow-head Cholesky of lm_optimizer.py:350-383,:597-603.
+ */
+#define GCLM_SHARED_PARTIAL_STRIDE 16
+int gclm_shared_begin(gclm_handle* h, const float* d_up, const float* d_lat, const float* d_up_conf,
+                      const float* d_lat_conf, int B_local, int H, int W, float* d_cam_io,
+                      float* d_grav_io, const int32_t* d_group_of_frame /* (B_local), non-decreasing */,
+                      int num_groups, void* stream);
+int gclm_shared_reduce(gclm_handle* h, int step, float* d_partials, void* stream);
+int gclm_shared_apply(gclm_handle* h, int step, const float* d_partials, void* stream);
+int gclm_shared_finish(gclm_handle* h, float* d_info_out, void* stream);
+
+/*
+ * Measurement helper (bench.py, tests): synthetic perspective fields generated on the device,
+ * SURVEY.md section 8(d).  Image i depends on (seed, first_index + i) only, so every sharding of
+ * a batch sees identical data.  Writes the 5 planes and the ground truth (B,8) / (B,3).
+ */
+int gclm_synth_fields(int camera_model, uint64_t seed, int64_t first_index, int B, int H, int W,
+                      float noise_sigma, float* d_up, float* d_lat, float* d_up_conf,
+                      float* d_lat_conf, float* d_gt_cam, float* d_gt_grav, void* stream);
+
+/* Timing helper: HIP-event elapsed milliseconds of the pass kernels of the last gclm_solve
+ * (recorded on the solve's stream when enabled).  Returns <0 if timing was not enabled. */
+int gclm_set_timing(gclm_handle* h, int enabled);
+int gclm_last_pass_timing(gclm_handle* h, int* n_launches, float* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCLM_H */
