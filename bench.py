@@ -1,0 +1,183 @@
+"""bench.py -- images/sec of complete LM calibrations on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch: a full LM calibration (num_steps=20 sweeps +
+final sweep with uncertainty) of `--batch` synthetic 640x480 images PER GPU (weak scaling: the
+global batch is batch x N; BASELINE configs[1] at N=1, configs[2] = 8192 images at N=8), followed
+for N>1 by the single RCCL all-gather of the packed results.  Inputs are generated on the device
+before the timed region (counter-based generator keyed by (seed, global image index)).
+
+    python bench.py                      # N=1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline:     achieved = algorithmic bytes of one sweep launch / mean sweep duration measured with
+                HIP events on the launch stream inside the timed region; peak = 8 TB/s HBM3E.
+  cpu_baseline: the CPU oracle (oracle/lm_oracle.c, a port of the reference algorithm) on a bounded
+                sample of the same workload, on this box's host cores (rank 0, N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+PLANES = 5                       # up_x, up_y, latitude, up_confidence, latitude_confidence
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1024, help="images per GPU")
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--camera-model", default="pinhole", choices=["pinhole", "simple_radial"])
+    ap.add_argument("--lm-steps", type=int, default=20)
+    ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="images for the CPU baseline (-1: auto, 0: skip)")
+    ap.add_argument("--no-timing", action="store_true", help="skip the in-library HIP-event timing of the sweeps")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, n_images):
+    """Oracle (C port of the reference algorithm, OpenMP over images) on a bounded sample."""
+    from oracle import lm_oracle, synth
+    cores = os.cpu_count() or 1
+    lm_oracle.build()
+    data, _, _ = synth.make_fields(args.seed, range(n_images), args.camera_model, args.height, args.width)
+    conf = {"camera_model": args.camera_model, "num_steps": args.lm_steps, "early_stop": False}
+    t0 = time.perf_counter()
+    lm_oracle.solve(data, conf, precision="f32", num_threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": round(n_images / dt, 3), "unit": "images/sec", "cores": min(cores, n_images), "kind": "port",
+            "sample": f"{n_images} images {args.width}x{args.height}, {args.lm_steps} LM iters, oracle/lm_oracle.c "
+                      f"(float32, OpenMP over images), {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from geocalib_amd import LMOptimizer, _lib
+    from geocalib_amd.parallel import calibrate_sharded
+
+    lib = _lib.load()
+    B, H, W = args.batch, args.height, args.width
+    n_total = B * world
+    up = torch.empty((B, 2, H, W), device=dev)
+    lat = torch.empty((B, 1, H, W), device=dev)
+    upc = torch.empty((B, H, W), device=dev)
+    latc = torch.empty((B, H, W), device=dev)
+    gt_cam = torch.empty((B, 8), device=dev)
+    gt_grav = torch.empty((B, 3), device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    rc = lib.gclm_synth_fields(_lib.CAMERA_MODEL_IDS[args.camera_model], args.seed, rank * B, B, H, W, 0.02,
+                               up.data_ptr(), lat.data_ptr(), upc.data_ptr(), latc.data_ptr(),
+                               gt_cam.data_ptr(), gt_grav.data_ptr(), stream)
+    assert rc == 0, rc
+    data = {"up_field": up, "latitude_field": lat, "up_confidence": upc, "latitude_confidence": latc}
+    opt = LMOptimizer({"camera_model": args.camera_model, "num_steps": args.lm_steps, "early_stop": False}).eval()
+
+    def step():
+        return calibrate_sharded(opt, data, n_total)
+
+    for _ in range(max(args.warmup, 1)):
+        out = step()
+    torch.cuda.synchronize()
+    handle = opt._handle(dev)
+    if not args.no_timing:
+        lib.gclm_set_timing(handle.ptr, 1)
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sweep_ms, sweep_n = 0.0, 0
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    if not args.no_timing:   # HIP events recorded around every sweep launch of the timed region
+        n, ms = C.c_int(0), C.c_float(0)
+        _lib.check(lib.gclm_last_pass_timing(handle.ptr, C.byref(n), C.byref(ms)), handle.ptr, "timing")
+        sweep_ms, sweep_n = ms.value, n.value
+
+    # sanity: the solve must have recovered the synthetic ground truth (a fast wrong answer is no answer)
+    cam = out["camera"]._data
+    lo = rank * B if cam.shape[0] == n_total else 0
+    f_err = (cam[lo:lo + B, 3] / gt_cam[:, 3] - 1).abs().median().item()
+    g_err = (out["gravity"]._data[lo:lo + B] - gt_grav).abs().max(1).values.median().item()
+    assert f_err < 5e-3 and g_err < 5e-3, (f_err, g_err)
+
+    if rank == 0:
+        value = n_total * args.steps / elapsed
+        algo_bytes_per_launch = B * H * W * PLANES * 4
+        result = {
+            "metric": "images/sec LM calibration (640x480, 20 iters)", "value": round(value, 1),
+            "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[{1 if world == 1 else 2}]: batch={B}/GPU ({n_total} total) "
+                                   f"synthetic {W}x{H} perspective fields, {args.camera_model}, "
+                                   f"{args.lm_steps} LM iters + final/uncertainty sweep, early_stop=False",
+                       "camera_model": args.camera_model, "global_batch": n_total, "per_gpu_batch": B,
+                       "height": H, "width": W, "lm_steps": args.lm_steps, "planes": PLANES,
+                       "parallelism": f"image-sharded x{world}, one all-gather of results" if world > 1 else "single GPU"},
+            "check": {"median_focal_rel_err_vs_gt": f_err, "median_gravity_abs_err_vs_gt": g_err},
+        }
+        if sweep_n:
+            avg_ms = sweep_ms / sweep_n
+            achieved = algo_bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):
+                with open(tpath) as fh:
+                    t = json.load(fh)
+                key = f"{args.camera_model}_B{B}_{W}x{H}"
+                traffic = t.get(key, {}).get("hbm_bytes_per_launch")
+            result["roofline"] = {
+                "bound": "hbm", "kernel": "gclm::sweep_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": algo_bytes_per_launch, "avg_launch_ms": round(avg_ms, 4),
+                "launches_timed": sweep_n,
+                "whole_job_frac": round(value / world * (args.lm_steps + 1) * H * W * PLANES * 4 / 1e9 / HBM_PEAK_GBS, 4)}
+        if world == 1 and args.cpu_sample != 0:
+            n = args.cpu_sample if args.cpu_sample > 0 else max(8, min(64, 2 * (os.cpu_count() or 1)))
+            try:
+                result["cpu_baseline"] = cpu_baseline(args, n)
+            except Exception as e:  # the checker must never take the product measurement down
+                result["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -249,7 +249,7 @@ class BaseCamera(TensorWrapper):
     @autocast
     def J_world2image(self, p3d: torch.Tensor):
         p2d, valid = self.project(p3d)
-        J = self.J_denormalize() @ self.J_distort(p2d) @ self.J_project(p3d)
+        J = self.J_denormalize().unsqueeze(-3) @ self.J_distort(p2d) @ self.J_project(p3d)
         return J, valid
 
     @autocast

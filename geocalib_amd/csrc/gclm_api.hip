@@ -122,7 +122,8 @@ SweepArgs sweep_args(const gclm_handle* h, const float* up, const float* lat, co
 
 int timed_sweep(gclm_handle* h, const SweepArgs& a, hipStream_t s) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (h->timing) {
+    const bool timing = h->timing && h->ev_used < 2 * 8192;   // bounded: stop recording silently
+    if (timing) {
         while ((int)h->ev.size() < h->ev_used + 2) {
             hipEvent_t e;
             GCLM_HIP(h, hipEventCreate(&e));
@@ -134,7 +135,7 @@ int timed_sweep(gclm_handle* h, const SweepArgs& a, hipStream_t s) {
         GCLM_HIP(h, hipEventRecord(e0, s));
     }
     GCLM_HIP(h, launch_sweep(h->cfg.camera_model, a, s));
-    if (h->timing) GCLM_HIP(h, hipEventRecord(e1, s));
+    if (timing) GCLM_HIP(h, hipEventRecord(e1, s));
     return 0;
 }
 
@@ -253,6 +254,7 @@ int gclm_last_pass_timing(gclm_handle* h, int* n_launches, float* total_ms) {
     }
     if (n_launches) *n_launches = h->ev_used / 2;
     if (total_ms) *total_ms = tot;
+    h->ev_used = 0;          // events accumulate over solves until read
     return 0;
 }
 
@@ -272,7 +274,6 @@ int gclm_solve(gclm_handle* h, const float* d_up, const float* d_lat, const floa
     c.B = B; c.H = H; c.W = W; c.nchunks = geo.nchunks;
     if (int rc = setup_groups(h, B)) return rc;
     if (int rc = ensure_workspace(h, B, geo.nchunks, c.n_groups)) return rc;
-    h->ev_used = 0;
     h->sh.active = false;
 
     GCLM_HIP(h, hipMemsetAsync(d_info_out, 0, sizeof(float) * GCLM_INFO_STRIDE * (size_t)B, s));
@@ -341,7 +342,6 @@ int gclm_shared_begin(gclm_handle* h, const float* d_up, const float* d_lat, con
     h->sh.up = d_up; h->sh.lat = d_lat; h->sh.upc = d_up_conf; h->sh.latc = d_lat_conf;
     h->sh.cam_io = d_cam_io; h->sh.grav_io = d_grav_io;
     h->sh.active = true;
-    h->ev_used = 0;
     GCLM_HIP(h, launch_init(c, d_cam_io, d_grav_io, s));
     return 0;
 }

@@ -200,6 +200,7 @@ class LMOptimizer(nn.Module):
             rc = _lib.load().gclm_solve(h.ptr, self._ptr(up), self._ptr(lat), self._ptr(upc), self._ptr(latc),
                                         B, H, W, cam.data_ptr(), grav.data_ptr(), info.data_ptr(), stream)
         _lib.check(rc, h.ptr, "gclm_solve")
+        self._last_raw = (cam, grav, info)     # packed device results (parallel.calibrate_sharded)
         return camera_opt.__class__(cam), Gravity(grav), self._unpack_info(info, up is not None)
 
     def _unpack_info(self, info: torch.Tensor, has_up: bool) -> Dict[str, torch.Tensor]:

@@ -1,0 +1,127 @@
+"""Multi-GPU calibration: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+Independent intrinsics (BASELINE config 3): images are independent, so the batch is sharded by
+contiguous image ranges, every rank solves its shard with ZERO communication, and the packed
+result rows (camera 8 + gravity 3 + infos 48 floats = 236 B/image) are exchanged with ONE
+all-gather.  The payload is KBs: latency-bound, so everything is packed into a single collective.
+
+Shared intrinsics with a group's frames split across ranks (BASELINE config 5): per LM step every
+rank reduces its frames to per-group Schur partials (16 floats/group, csrc/gclm_update.hip), ONE
+all-reduce(sum) over all groups, then every rank solves the tiny Schur systems redundantly and
+updates its own frames.  The reference has no counterpart (its LM is single-process): parity is
+checked on the gathered results against the single-process oracle.
+"""
+from typing import Dict, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .camera import BaseCamera
+from .gravity import Gravity
+from .lm_optimizer import LMOptimizer, _dev_f32, get_trivial_estimation
+
+ROW = 8 + 3 + _lib.INFO_STRIDE   # packed floats per image
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [lo, hi) of `n` items owned by `rank` (sizes differ by at most one)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pack_rows(cam: torch.Tensor, grav: torch.Tensor, info: torch.Tensor) -> torch.Tensor:
+    return torch.cat([cam, grav, info], dim=1).contiguous()
+
+
+def unpack_rows(rows: torch.Tensor):
+    return rows[:, :8], rows[:, 8:11], rows[:, 11:11 + _lib.INFO_STRIDE]
+
+
+def all_gather_rows(rows: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """ONE all-gather of the per-image result rows of every rank -> (n_total, ROW), rank order.
+    Shards may differ by one row: rows are padded to the largest shard for the collective."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    cap = (n_total + world - 1) // world
+    buf = rows.new_zeros((cap, rows.shape[1]))
+    buf[: rows.shape[0]] = rows
+    out = rows.new_empty((world * cap, rows.shape[1]))
+    dist.all_gather_into_tensor(out, buf, group=group)
+    parts = []
+    for r in range(world):
+        lo, hi = shard_range(n_total, r, world)
+        parts.append(out[r * cap: r * cap + (hi - lo)])
+    assert parts[rank].shape[0] == rows.shape[0]
+    return torch.cat(parts, 0)
+
+
+def infos_from_rows(opt: LMOptimizer, rows: torch.Tensor, has_up: bool) -> Dict[str, torch.Tensor]:
+    cam, grav, info = unpack_rows(rows)
+    out = {"camera": opt.camera_model(cam.contiguous()), "gravity": Gravity(grav.contiguous())}
+    out.update(opt._unpack_info(info, has_up))
+    return out
+
+
+def calibrate_sharded(opt: LMOptimizer, local_data: Dict[str, torch.Tensor], n_total: int,
+                      group=None) -> Dict[str, torch.Tensor]:
+    """Solve this rank's shard (independent intrinsics) and all-gather everybody's results.
+
+    `local_data` holds the fields of the images [shard_range(n_total, rank, world)) of the global
+    batch; the returned dict covers all `n_total` images on every rank."""
+    assert not opt.shared_intrinsics, "use SharedIntrinsicsSplit for shared intrinsics"
+    out = opt(local_data)
+    rows = pack_rows(*opt._last_raw)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        rows = all_gather_rows(rows, n_total, group)
+        return infos_from_rows(opt, rows, "up_field" in local_data)
+    return out
+
+
+class SharedIntrinsicsSplit:
+    """Shared-intrinsics LM where each group's frames are spread over the ranks of `group`.
+
+    Every rank holds `local_data` (its frames, sorted by group id) and `group_of_frame`
+    (int32, non-decreasing, values in [0, num_groups)).  Per step: local sweep + Schur partials
+    (gclm_shared_reduce) -> ONE all-reduce(sum) of (num_groups, 16) floats -> solve + update
+    (gclm_shared_apply)."""
+
+    def __init__(self, opt: LMOptimizer, num_groups: int, group=None):
+        assert opt.shared_intrinsics, "optimizer must be configured with shared_intrinsics=True"
+        assert not opt.conf.early_stop, "split shared intrinsics runs a fixed number of steps"
+        self.opt, self.num_groups, self.group = opt, num_groups, group
+
+    def __call__(self, local_data: Dict[str, torch.Tensor], group_of_frame: torch.Tensor):
+        opt, lib = self.opt, _lib.load()
+        with torch.no_grad():
+            cam0, grav0 = get_trivial_estimation(local_data, opt.camera_model)
+            opt.setup_optimization_and_priors(local_data, shared_intrinsics=True)
+            up, lat, upc, latc, (B, H, W) = opt._fields(local_data)
+            dev = lat.device
+            h = opt._handle(dev)
+            cam = _dev_f32(cam0._data, "camera").clone()
+            grav = _dev_f32(grav0._data, "gravity").clone()
+            gof = group_of_frame.to(device=dev, dtype=torch.int32).contiguous()
+            partials = torch.zeros((self.num_groups, _lib.SHARED_PARTIAL_STRIDE), dtype=torch.float32, device=dev)
+            info = torch.empty((B, _lib.INFO_STRIDE), dtype=torch.float32, device=dev)
+            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+            with torch.cuda.device(dev):
+                s = torch.cuda.current_stream(dev).cuda_stream
+                P = opt._ptr
+                _lib.check(lib.gclm_shared_begin(h.ptr, P(up), P(lat), P(upc), P(latc), B, H, W, cam.data_ptr(),
+                                                 grav.data_ptr(), gof.data_ptr(), self.num_groups, s), h.ptr,
+                           "gclm_shared_begin")
+                for step in range(opt.num_steps):
+                    _lib.check(lib.gclm_shared_reduce(h.ptr, step, partials.data_ptr(), s), h.ptr, "gclm_shared_reduce")
+                    if multi:
+                        dist.all_reduce(partials, op=dist.ReduceOp.SUM, group=self.group)
+                    _lib.check(lib.gclm_shared_apply(h.ptr, step, partials.data_ptr(), s), h.ptr, "gclm_shared_apply")
+                _lib.check(lib.gclm_shared_finish(h.ptr, info.data_ptr(), s), h.ptr, "gclm_shared_finish")
+        out = {"camera": cam0.__class__(cam), "gravity": Gravity(grav)}
+        out.update(opt._unpack_info(info, up is not None))
+        return out
+
+
+__all__ = ["shard_range", "pack_rows", "unpack_rows", "all_gather_rows", "calibrate_sharded",
+           "SharedIntrinsicsSplit", "ROW", "BaseCamera"]

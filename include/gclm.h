@@ -155,8 +155,9 @@ int gclm_synth_fields(int camera_model, uint64_t seed, int64_t first_index, int 
                       float noise_sigma, float* d_up, float* d_lat, float* d_up_conf,
                       float* d_lat_conf, float* d_gt_cam, float* d_gt_grav, void* stream);
 
-/* Timing helper: HIP-event elapsed milliseconds of the pass kernels of the last gclm_solve
- * (recorded on the solve's stream when enabled).  Returns <0 if timing was not enabled. */
+/* Timing helper: when enabled, every sweep launch is bracketed by HIP events on the solve's stream;
+ * gclm_last_pass_timing waits for the recorded launches, returns their count and summed duration
+ * since the previous read, and resets the record.  Returns <0 if timing was not enabled. */
 int gclm_set_timing(gclm_handle* h, int enabled);
 int gclm_last_pass_timing(gclm_handle* h, int* n_launches, float* total_ms);
 

@@ -1,0 +1,101 @@
+"""CPU: the C-ABI shared library loads and exports every symbol include/gclm.h declares.
+No compute calls here (no GPU in this container): gclm_create must FAIL LOUDLY without a device."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+from geocalib_amd import _lib
+
+HEADER = os.path.join(ROOT, "include", "gclm.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gclm_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_is_built_in_tree():
+    assert os.path.exists(_lib.LIB_PATH), "run `python __graft_entry__.py` (build()) first"
+    assert os.path.realpath(_lib.LIB_PATH).startswith(os.path.realpath(ROOT))
+
+
+def test_header_symbols_are_exported_and_bound():
+    names = declared_symbols()
+    assert len(names) >= 15
+    lib = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/gclm.h but not exported"
+    assert set(names) == set(_lib.EXPORTED_SYMBOLS), "ctypes binding and header disagree"
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (gclm_\w+)", out))
+    assert exported == set(names), exported ^ set(names)
+
+
+def test_code_object_targets_gfx950():
+    """The embedded device code must be gfx950 (no other arch, no generic fallback)."""
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    for other in (b"gfx942", b"gfx90a", b"gfx1100", b"sm_90"):
+        assert other not in blob
+
+
+def test_default_config_matches_reference_defaults():
+    lib = _lib.load()
+    assert lib.gclm_version() == 100
+    cfg = _lib.GclmConfig()
+    assert lib.gclm_default_config(C.byref(cfg)) == 0
+    # LMOptimizer.default_conf, lm_optimizer.py:144-162
+    assert (cfg.camera_model, cfg.shared_intrinsics, cfg.num_steps, cfg.fix_lambda, cfg.early_stop) == (0, 0, 30, 0, 1)
+    assert cfg.lambda0 == pytest.approx(0.1) and cfg.atol == pytest.approx(1e-8) and cfg.rtol == pytest.approx(1e-8)
+    assert cfg.use_spherical_manifold == 1 and cfg.use_log_focal == 1
+    assert cfg.up_loss_fn_scale == pytest.approx(1e-2) and cfg.lat_loss_fn_scale == pytest.approx(1e-2)
+    assert cfg.estimate_gravity == cfg.estimate_focal == cfg.estimate_dist == cfg.compute_uncertainty == 1
+    assert C.sizeof(_lib.GclmConfig) == 17 * 4
+
+
+def test_create_rejects_bad_config_with_message():
+    lib = _lib.load()
+    cfg = _lib.GclmConfig()
+    lib.gclm_default_config(C.byref(cfg))
+    cfg.camera_model = 7
+    h = C.c_void_p()
+    assert lib.gclm_create(C.byref(h), C.byref(cfg), 0) != 0 and not h
+    assert "camera_model" in _lib.last_error(None)
+    lib.gclm_default_config(C.byref(cfg))
+    cfg.num_steps = 100000
+    assert lib.gclm_create(C.byref(h), C.byref(cfg), 0) != 0
+    assert "num_steps" in _lib.last_error(None)
+
+
+def test_no_cpu_fallback():
+    """Without a HIP device the product path must refuse to run (and say why), never fall back."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    lib = _lib.load()
+    cfg = _lib.GclmConfig()
+    lib.gclm_default_config(C.byref(cfg))
+    h = C.c_void_p()
+    assert lib.gclm_create(C.byref(h), C.byref(cfg), 0) != 0
+    assert "no HIP device" in _lib.last_error(None)
+    from geocalib_amd import LMOptimizer
+    data = {"up_field": torch.zeros(1, 2, 8, 8), "latitude_field": torch.zeros(1, 1, 8, 8)}
+    with pytest.raises(RuntimeError, match="HIP device"):
+        LMOptimizer({})(data)
+
+
+def test_product_package_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under geocalib_amd/ may import, link or load it."""
+    pkg = os.path.join(ROOT, "geocalib_amd")
+    pat = re.compile(r"lm_oracle|from\s+oracle|import\s+oracle|oracle/|liblm_oracle|ref_import")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not pat.search(txt), (dirpath, f, pat.search(txt).group(0))

@@ -1,0 +1,149 @@
+"""CPU, world_size 2 (gloo): the multi-process plumbing of geocalib_amd.parallel.
+
+(1) the single all-gather of packed per-image result rows (uneven shards, rank order);
+(2) the algebra behind the shared-intrinsics split (BASELINE config 5): per-rank Schur partials summed
+    with ONE all-reduce reproduce the reference's dense arrow-head Cholesky step.  The per-frame
+    systems come from the oracle, the dense solve is restated from lm_optimizer.py:350-383,:109-137,
+    and step 0 is also compared with the reference's recorded delta (tests/golden/golden_trace.npz).
+The GPU kernels that produce / consume these partials are covered by the -m gpu tests."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import GOLDEN, conf_for, data_for
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(fn, world, *args):
+    port = _free_port()
+    mp.spawn(_entry, args=(fn, world, port, args), nprocs=world, join=True)
+
+
+def _entry(rank, fn, world, port, args):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fn(rank, world, *args)
+    finally:
+        dist.destroy_process_group()
+
+
+def _gather_worker(rank, world, n_total):
+    from geocalib_amd.parallel import ROW, all_gather_rows, shard_range, unpack_rows
+    lo, hi = shard_range(n_total, rank, world)
+    rows = torch.arange(lo, hi, dtype=torch.float32)[:, None] * torch.ones(1, ROW) + torch.arange(ROW) * 1e-3
+    full = all_gather_rows(rows, n_total)
+    assert full.shape == (n_total, ROW)
+    expect = torch.arange(n_total, dtype=torch.float32)[:, None] + torch.arange(ROW) * 1e-3
+    assert torch.allclose(full, expect)
+    cam, grav, info = unpack_rows(full)
+    assert cam.shape[1] == 8 and grav.shape[1] == 3 and info.shape[1] == 48
+
+
+def test_shard_ranges_cover_batch():
+    from geocalib_amd.parallel import shard_range
+    for n in (0, 1, 7, 8, 1024, 8191):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_all_gather_rows_world2_uneven():
+    _run(_gather_worker, 2, 5)
+
+
+def test_all_gather_rows_world2_even():
+    _run(_gather_worker, 2, 8)
+
+
+def _damped(H, lam):
+    return H + np.diag(np.maximum(np.diag(H) * lam, 1e-6))
+
+
+def _dense_arrowhead_delta(Hs, Gs, lam, ni):
+    """Reference path: assemble the (2B+ni) system (lm_optimizer.py:350-383), damp, Cholesky (:109-137)."""
+    B = Hs.shape[0]
+    n = 2 * B + ni
+    A, g = np.zeros((n, n)), np.zeros(n)
+    for b in range(B):
+        A[2 * b:2 * b + 2, 2 * b:2 * b + 2] = Hs[b, :2, :2]
+        A[2 * b:2 * b + 2, 2 * B:] = Hs[b, :2, 2:]
+        A[2 * B:, 2 * b:2 * b + 2] = Hs[b, 2:, :2]
+        A[2 * B:, 2 * B:] += Hs[b, 2:, 2:]
+        g[2 * b:2 * b + 2] = Gs[b, :2]
+        g[2 * B:] += Gs[b, 2:]
+    L = np.linalg.cholesky(_damped(A, lam))
+    return np.linalg.solve(L.T, np.linalg.solve(L, g))
+
+
+def _schur_worker(rank, world, setname, q):
+    from oracle import lm_oracle
+    from geocalib_amd.parallel import shard_range
+    data, conf = data_for(setname, "bench"), conf_for(setname, "bench")
+    B = data["latitude_field"].shape[0]
+    ni = 1 if "pinhole" in setname else 2
+    init = lm_oracle.solve(data, {**conf, "num_steps": 0})           # trivial estimate
+    sysm = lm_oracle.system(data, init["camera"], init["gravity"], conf, precision="f64")
+    Hs, Gs, lam = sysm["H"], sysm["G"], 0.1
+    lo, hi = shard_range(B, rank, world)
+    # local Schur partials, layout of gclm_update.hip::shared_group_kernel
+    part = np.zeros(16)
+    for b in range(lo, hi):
+        Dinv = np.linalg.inv(_damped(Hs[b, :2, :2], lam))
+        E = Hs[b, :2, 2:]
+        part[0:ni * ni] += (E.T @ Dinv @ E).ravel() if ni == 1 else 0
+        if ni == 2:
+            part[0:4] += (E.T @ Dinv @ E).ravel()
+        part[4:4 + ni] += E.T @ Dinv @ Gs[b, :2]
+        C = Hs[b, 2:, 2:]
+        if ni == 1:
+            part[6] += C[0, 0]
+        else:
+            part[6:10] += C.ravel()
+        part[10:10 + ni] += Gs[b, 2:]
+    t = torch.from_numpy(part)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)                          # the ONE collective per step
+    part = t.numpy()
+    if ni == 1:
+        S = np.array([[part[6] - part[0]]]) + np.diag(np.maximum(np.array([part[6]]) * lam, 1e-6))
+    else:
+        C = part[6:10].reshape(2, 2)
+        S = C - part[0:4].reshape(2, 2) + np.diag(np.maximum(np.diag(C) * lam, 1e-6))
+    dI = np.linalg.solve(S, part[10:10 + ni] - part[4:4 + ni])
+    dG = np.stack([np.linalg.inv(_damped(Hs[b, :2, :2], lam)) @ (Gs[b, :2] - Hs[b, :2, 2:] @ dI) for b in range(lo, hi)])
+    dense = _dense_arrowhead_delta(Hs, Gs, lam, ni)
+    assert np.allclose(dI, dense[2 * B:], rtol=1e-9, atol=1e-12)
+    assert np.allclose(dG.ravel(), dense[2 * lo:2 * hi], rtol=1e-9, atol=1e-12)
+    if rank == 0:
+        q.put((dI, dense))
+
+
+def _check_schur(setname):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    _run(_schur_worker, 2, setname, q)
+    dI, dense = q.get()
+    tr = np.load(os.path.join(GOLDEN, "golden_trace.npz"))
+    ref_delta = tr[f"{setname}/delta"][0][0]                          # the reference's own step-0 delta
+    assert np.allclose(dense, ref_delta, rtol=2e-3, atol=2e-5)
+    assert np.allclose(dI, ref_delta[-len(dI):], rtol=2e-3, atol=2e-5)
+
+
+def test_schur_split_equals_dense_arrowhead_pinhole():
+    _check_schur("shared_pinhole")
+
+
+def test_schur_split_equals_dense_arrowhead_simple_radial():
+    _check_schur("shared_simple_radial")
