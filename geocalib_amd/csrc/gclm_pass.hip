@@ -1,4 +1,4 @@
-// gclm_pass.hip -- the fused per-pixel sweep (the HBM-bound hot kernel), gfx950.
+// gclm_pass.hip -- the fused per-pixel sweep (the hot kernel), gfx950.
 //
 // One launch evaluates, for every image of the batch at its current parameters, in ONE pass over
 // the 3..5 input planes:
@@ -13,173 +13,208 @@
 //   u=(x-cx)/fx, v=(y-cy)/fy, r2=u^2+v^2
 //   UP   p=(a-c u, b-c v); d=1+k1 r2; t=u px+v py; q=d p+2 k1 t (u,v)  (pinhole: q=p); up=q/|q|
 //        d(up)/d(theta) = n (n . dq/dtheta)/|q| with n=(-up_y, up_x)  [I - up up^T = n n^T in 2-D]
-//        => the 2 x P up-Jacobian is rank one: J_up = n s^T,  J^T J = s s^T,  J^T r = s (n . r)
+//        => the 2 x P up-Jacobian is rank one: J_up = n s^T,  J^T J = s s^T,  J^T r = s (n . r);
+//        dq/dtheta = M dp/dtheta + ..., M = d I + 2 k1 uv uv^T symmetric => s_k = (M nq).dp/dtheta_k
 //   LAT  e=1-k1 r2; P=e (u,v); ray=(P,1)/sqrt(|P|^2+1); s=ray.g; r_lat=sin(lat_data)-clamp(s)
 //        ds/d(delta_k)=ray.T[:,k];  ds/df=h.(e w-2 k1 (u,v)(uv.w));  ds/dk1=h.(-r2 (u,v)),
 //        h=(g_xy-s ray_xy)/sqrt(|P|^2+1),  w=(-u wfx,-v wfy)
 //
 // Mapping to the machine: grid = (chunks per image, B); a 256-thread workgroup (4 waves of 64)
 // streams a contiguous run of float4 groups of one image with fully coalesced 16 B/lane loads
-// (1 KiB per wave-instruction per plane), the 64-byte parameter block of the image is read with
-// scalar loads (workgroup-uniform -> SGPRs), 16 fp32 accumulators per lane are reduced with
-// wave64 DPP shuffles, then across the 4 waves through LDS, and ONE 64-byte partial record per
-// workgroup is written (no atomics: bit-reproducible).  No MFMA: the contraction is N x P -> P x P
-// with P <= 4.
+// (1 KiB per wave-instruction per plane); the 64-byte parameter block of the image is read with
+// scalar loads (workgroup-uniform -> SGPRs); 16 accumulators per lane are reduced with wave64
+// shuffles, then across the 4 waves through LDS, and ONE 64-byte partial record per workgroup is
+// written (no atomics: bit-reproducible).  No MFMA: the contraction is N x P -> P x P with P <= 4.
+//
+// Arithmetic: PMC counters (profiles/r01_pmc_sq_*) show the sweep is VALU-issue-bound as soon as
+// it approaches ~6 TB/s (scalar fp32 FMA sustains ~1 wave64 instruction / 3 cycles / SIMD), so the
+// float4 path computes PIXEL PAIRS in packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32:
+// two pixels per instruction) -- written explicitly on a 2-wide vector type so the pairs live in
+// adjacent registers straight out of the dwordx4 loads (LLVM's SLP vectoriser finds some of these
+// pairs on its own but pays for them with register shuffles and 2x the VGPRs; it is switched off for
+// this file, see the Makefile).
 #include "gclm_internal.h"
 
 namespace gclm {
 
 namespace {
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// ---- lane-vector helpers: the per-pixel math below is written once for F = float (scalar path)
+// ---- and F = f2 (two horizontally adjacent pixels per lane, packed fp32)
+__device__ __forceinline__ float vfma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ f2 vfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float vrsq(float a) { return __frsqrt_rn(a); }
+__device__ __forceinline__ f2 vrsq(f2 a) { return f2{__frsqrt_rn(a.x), __frsqrt_rn(a.y)}; }
+__device__ __forceinline__ float vmax(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ f2 vmax(f2 a, f2 b) { return f2{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
+__device__ __forceinline__ float vclamp(float a, float lo, float hi) { return fminf(fmaxf(a, lo), hi); }
+__device__ __forceinline__ f2 vclamp(f2 a, float lo, float hi) {
+    return f2{fminf(fmaxf(a.x, lo), hi), fminf(fmaxf(a.y, lo), hi)};
+}
+// select(y <= 1, a, b)
+__device__ __forceinline__ float vsel_le1(float y, float a, float b) { return y <= 1.0f ? a : b; }
+__device__ __forceinline__ f2 vsel_le1(f2 y, f2 a, f2 b) {
+    return f2{y.x <= 1.0f ? a.x : b.x, y.y <= 1.0f ? a.y : b.y};
+}
+__device__ __forceinline__ float vsplat(float, float s) { return s; }
+__device__ __forceinline__ f2 vsplat(f2, float s) { return f2{s, s}; }
+__device__ __forceinline__ float hsum(float a) { return a; }
+__device__ __forceinline__ float hsum(f2 a) { return a.x + a.y; }
+
 // sin(x) for |x| <= pi/2 (odd minimax polynomial, |err| < 1.2e-7 in fp32).  Latitudes are
 // asin(clamp(tanh)) outputs of the CNN head (geocalib.py:73-75) and therefore in range.
-__device__ __forceinline__ float sin_halfpi(float x) {
-    const float t = x * x;
-    float p = 2.6000457182817627e-06f;
-    p = fmaf(p, t, -0.00019806611817330122f);
-    p = fmaf(p, t, 0.008333017118275166f);
-    p = fmaf(p, t, -0.16666656732559204f);
-    return fmaf(x * t, p, x);
+template <typename F>
+__device__ __forceinline__ F sin_halfpi(F x) {
+    const F t = x * x;
+    F p = vsplat(x, 2.6000457182817627e-06f);
+    p = vfma(p, t, vsplat(x, -0.00019806611817330122f));
+    p = vfma(p, t, vsplat(x, 0.008333017118275166f));
+    p = vfma(p, t, vsplat(x, -0.16666656732559204f));
+    return vfma(x * t, p, x);
 }
 
-// Scaled Huber on the squared residual x2 (lm_optimizer.py:61-87): returns cost, sets weight.
-__device__ __forceinline__ float huber(float x2, float inv_a2, float a2, float& weight) {
-    const float y = x2 * inv_a2;
-    const float yy = y + 1e-8f;
-    const float isx = __frsqrt_rn(yy);
-    const float sx = yy * isx;
-    const bool inl = y <= 1.0f;
-    weight = inl ? 1.0f : fmaxf(isx, 1.1920928955078125e-07f);
-    return (inl ? y : fmaf(2.0f, sx, -1.0f)) * a2;
+// Scaled Huber on the squared residual x2 (lm_optimizer.py:61-87), in units of a^2: returns
+// cost / a^2 (the a^2 factor is applied once per workgroup) and sets the weight.
+// The reference's max(eps, 1/sqrt(y)) only matters for y > 7e13; residuals here are bounded
+// (|r_up| <= 2, |r_lat| <= 2 => y <= 4/a^2), so it is the identity and is dropped.
+template <typename F>
+__device__ __forceinline__ F huber(F x2, float inv_a2, F& weight) {
+    const F y = x2 * inv_a2;
+    const F yy = y + 1e-8f;
+    const F isx = vrsq(yy);
+    weight = vsel_le1(y, vsplat(y, 1.0f), isx);
+    return vsel_le1(y, y, vfma(2.0f * yy, isx, vsplat(y, -1.0f)));
 }
 
 struct HuberK {
     float inv_a2u, a2u, inv_a2l, a2l;
 };
 
-template <int MODEL, bool HAS_UP>
-__device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& hk, float xf, float yf,
-                                                 float dux, float duy, float dlat, float cu, float cl,
-                                                 float (&acc)[kNAcc]) {
+template <int MODEL, bool HAS_UP, typename F>
+__device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& hk, F xf, float yf, F dux, F duy,
+                                                 F dlat, F cu, F cl, F (&acc)[kNAcc]) {
     constexpr bool DIST = MODEL != GCLM_PINHOLE;
-    const float u = (xf - P.cx) * P.ifx;
-    const float v = (yf - P.cy) * P.ify;
-    const float r2 = fmaf(u, u, v * v);
-    const float wx = -u * P.wfx, wy = -v * P.wfy;      // d(uv)/d(focal parameter)
-    const float uvw = fmaf(u, wx, v * wy);
+    const F u = (xf - P.cx) * P.ifx;
+    const float v = (yf - P.cy) * P.ify;                 // one image row per tile: v is lane-scalar
+    const F r2 = vfma(u, u, vsplat(u, v * v));
+    const F wx = u * (-P.wfx);                           // d(uv)/d(focal parameter) = (wx, wy)
+    const float wy = -v * P.wfy;
+    const F uvw = vfma(u, wx, vsplat(u, v * wy));
     const float k1x2 = 2.0f * P.k1;
 
     if constexpr (HAS_UP) {
-        const float px = fmaf(-P.gc, u, P.ga), py = fmaf(-P.gc, v, P.gb);
-        // d p / d delta_k = (T0k - u T2k, T1k - v T2k)
-        float a0 = fmaf(-u, P.T20, P.T00), b0 = fmaf(-v, P.T20, P.T10);
-        float a1 = fmaf(-u, P.T21, P.T01), b1 = fmaf(-v, P.T21, P.T11);
-        float qx = px, qy = py;
-        float fx_ = -P.gc * wx, fy_ = -P.gc * wy;      // dq/df (pinhole)
-        float kx = 0.f, ky = 0.f;
+        const F px = vfma(u, vsplat(u, -P.gc), vsplat(u, P.ga));
+        const float py = fmaf(-P.gc, v, P.gb);
+        F qx = px, qy = vsplat(u, py), d = vsplat(u, 1.0f), t = vsplat(u, 0.f);
         if constexpr (DIST) {
-            const float d = fmaf(P.k1, r2, 1.0f);
-            const float t = fmaf(u, px, v * py);
-            const float kt = k1x2 * t;
-            qx = fmaf(d, px, kt * u);
-            qy = fmaf(d, py, kt * v);
-            // M z = d z + 2 k1 (u zx + v zy)(u,v)
-            float m;
-            m = k1x2 * fmaf(u, a0, v * b0); a0 = fmaf(d, a0, m * u); b0 = fmaf(d, b0, m * v);
-            m = k1x2 * fmaf(u, a1, v * b1); a1 = fmaf(d, a1, m * u); b1 = fmaf(d, b1, m * v);
-            const float mw = k1x2 * uvw;
-            const float Mwx = fmaf(d, wx, mw * u), Mwy = fmaf(d, wy, mw * v);
-            const float pw = fmaf(px, wx, py * wy);
-            // dq/df = -c M w + 2 k1 [ p (uv.w) + t w + (u,v)(p.w) ]
-            fx_ = fmaf(-P.gc, Mwx, k1x2 * (fmaf(px, uvw, fmaf(t, wx, u * pw))));
-            fy_ = fmaf(-P.gc, Mwy, k1x2 * (fmaf(py, uvw, fmaf(t, wy, v * pw))));
-            // dq/dk1 = r2 p + 2 t (u,v)
-            kx = fmaf(r2, px, 2.0f * t * u);
-            ky = fmaf(r2, py, 2.0f * t * v);
+            d = vfma(r2, vsplat(u, P.k1), vsplat(u, 1.0f));
+            t = vfma(u, px, vsplat(u, v * py));
+            const F kt = t * k1x2;
+            qx = vfma(d, px, kt * u);
+            qy = vfma(d, vsplat(u, py), kt * v);
         }
-        const float n2 = fmaxf(fmaf(qx, qx, qy * qy), 1e-24f);
-        const float rn = __frsqrt_rn(n2);
-        const float ux = qx * rn, uy = qy * rn;          // predicted up vector
-        const float rx = dux - ux, ry = duy - uy;        // residual (lm_optimizer.py:266)
-        const float x2 = fmaf(rx, rx, ry * ry);
-        float wgt;
-        float cost = huber(x2, hk.inv_a2u, hk.a2u, wgt);
-        wgt *= cu;
-        cost *= cu;
-        acc[A_CU] += cost;
-        // rank-one Jacobian: s_k = (n . dq_k)/|q|,  n = (-uy, ux);  rho = n . r
-        const float nx = -uy * rn, ny = ux * rn;
-        const float s0 = fmaf(nx, a0, ny * b0);
-        const float s1 = fmaf(nx, a1, ny * b1);
-        const float s2 = fmaf(nx, fx_, ny * fy_);
-        const float rho = fmaf(-uy, rx, ux * ry);
-        const float w0 = wgt * s0, w1 = wgt * s1, w2 = wgt * s2;
-        acc[A_G0 + 0] = fmaf(w0, rho, acc[A_G0 + 0]);
-        acc[A_G0 + 1] = fmaf(w1, rho, acc[A_G0 + 1]);
-        acc[A_G0 + 2] = fmaf(w2, rho, acc[A_G0 + 2]);
-        acc[A_H00 + 0] = fmaf(w0, s0, acc[A_H00 + 0]);
-        acc[A_H00 + 1] = fmaf(w0, s1, acc[A_H00 + 1]);
-        acc[A_H00 + 2] = fmaf(w0, s2, acc[A_H00 + 2]);
-        acc[A_H00 + 4] = fmaf(w1, s1, acc[A_H00 + 4]);
-        acc[A_H00 + 5] = fmaf(w1, s2, acc[A_H00 + 5]);
-        acc[A_H00 + 7] = fmaf(w2, s2, acc[A_H00 + 7]);
+        const F n2 = vmax(vfma(qx, qx, qy * qy), vsplat(u, 1e-24f));
+        const F rn = vrsq(n2);
+        const F ux = qx * rn, uy = qy * rn;              // predicted up vector
+        const F rx = dux - ux, ry = duy - uy;            // residual (lm_optimizer.py:266)
+        const F x2 = vfma(rx, rx, ry * ry);
+        F wgt;
+        const F cost = huber(x2, hk.inv_a2u, wgt);
+        wgt = wgt * cu;
+        acc[A_CU] = vfma(cost, cu, acc[A_CU]);
+        // rank-one Jacobian: s_k = (M nq) . dp/dtheta_k, nq = n/|q|, n = (-uy, ux);  rho = n . r
+        const F nx = -uy * rn, ny = ux * rn;
+        const F nuv = vfma(nx, u, ny * v);
+        const F nw = vfma(nx, wx, ny * wy);
+        F mx = nx, my = ny, muv = nuv, mw = nw;
         if constexpr (DIST) {
-            const float s3 = fmaf(nx, kx, ny * ky);
-            const float w3 = wgt * s3;
-            acc[A_G0 + 3] = fmaf(w3, rho, acc[A_G0 + 3]);
-            acc[A_H00 + 3] = fmaf(w0, s3, acc[A_H00 + 3]);
-            acc[A_H00 + 6] = fmaf(w1, s3, acc[A_H00 + 6]);
-            acc[A_H00 + 8] = fmaf(w2, s3, acc[A_H00 + 8]);
-            acc[A_H00 + 9] = fmaf(w3, s3, acc[A_H00 + 9]);
+            const F c2 = nuv * k1x2;
+            mx = vfma(d, nx, c2 * u);
+            my = vfma(d, ny, c2 * v);
+            muv = vfma(mx, u, my * v);
+            mw = vfma(mx, wx, my * wy);
+        }
+        // dp/ddelta_k = (T0k - u T2k, T1k - v T2k)  =>  s_k = m.T[0:2,k] - (m.uv) T2k
+        const F s0 = vfma(mx, vsplat(u, P.T00), vfma(my, vsplat(u, P.T10), muv * (-P.T20)));
+        const F s1 = vfma(mx, vsplat(u, P.T01), vfma(my, vsplat(u, P.T11), muv * (-P.T21)));
+        F s2 = mw * (-P.gc);                             // dp/df = -c w
+        [[maybe_unused]] F s3 = vsplat(u, 0.f);
+        if constexpr (DIST) {
+            // + 2 k1 [ p (uv.w) + t w + (u,v)(p.w) ] . nq          (perspective_fields.py:146-153)
+            const F np_ = vfma(nx, px, ny * py);
+            const F pw = vfma(px, wx, vsplat(u, py * wy));
+            s2 = vfma(vfma(np_, uvw, vfma(t, nw, nuv * pw)), vsplat(u, k1x2), s2);
+            s3 = vfma(r2, np_, (t * 2.0f) * nuv);        // dq/dk1 = r2 p + 2 t (u,v)   (:170-180)
+        }
+        const F rho = vfma(ux, ry, -(uy * rx));
+        const F w0 = wgt * s0, w1 = wgt * s1, w2 = wgt * s2;
+        acc[A_G0 + 0] = vfma(w0, rho, acc[A_G0 + 0]);
+        acc[A_G0 + 1] = vfma(w1, rho, acc[A_G0 + 1]);
+        acc[A_G0 + 2] = vfma(w2, rho, acc[A_G0 + 2]);
+        acc[A_H00 + 0] = vfma(w0, s0, acc[A_H00 + 0]);
+        acc[A_H00 + 1] = vfma(w0, s1, acc[A_H00 + 1]);
+        acc[A_H00 + 2] = vfma(w0, s2, acc[A_H00 + 2]);
+        acc[A_H00 + 4] = vfma(w1, s1, acc[A_H00 + 4]);
+        acc[A_H00 + 5] = vfma(w1, s2, acc[A_H00 + 5]);
+        acc[A_H00 + 7] = vfma(w2, s2, acc[A_H00 + 7]);
+        if constexpr (DIST) {
+            const F w3 = wgt * s3;
+            acc[A_G0 + 3] = vfma(w3, rho, acc[A_G0 + 3]);
+            acc[A_H00 + 3] = vfma(w0, s3, acc[A_H00 + 3]);
+            acc[A_H00 + 6] = vfma(w1, s3, acc[A_H00 + 6]);
+            acc[A_H00 + 8] = vfma(w2, s3, acc[A_H00 + 8]);
+            acc[A_H00 + 9] = vfma(w3, s3, acc[A_H00 + 9]);
         }
     }
 
     {   // latitude
-        float Px = u, Py = v, e = 1.0f;
+        F Px = u, Py = vsplat(u, v), e = vsplat(u, 1.0f);
         if constexpr (DIST) {
-            e = fmaf(-P.k1, r2, 1.0f);
+            e = vfma(r2, vsplat(u, -P.k1), vsplat(u, 1.0f));
             Px = e * u;
             Py = e * v;
         }
-        const float nn = fmaf(Px, Px, fmaf(Py, Py, 1.0f));
-        const float rnn = __frsqrt_rn(nn);
-        const float rayx = Px * rnn, rayy = Py * rnn;   // rayz = rnn
-        const float s = fmaf(rayx, P.ga, fmaf(rayy, P.gb, rnn * P.gc));
-        const float sc = fminf(fmaxf(s, -1.0f + 1e-6f), 1.0f - 1e-6f);
-        const float rl = sin_halfpi(dlat) - sc;          // lm_optimizer.py:262,270-271
-        float wgt;
-        float cost = huber(rl * rl, hk.inv_a2l, hk.a2l, wgt);
-        wgt *= cl;
-        cost *= cl;
-        acc[A_CL] += cost;
-        const float l0 = fmaf(rayx, P.T00, fmaf(rayy, P.T10, rnn * P.T20));
-        const float l1 = fmaf(rayx, P.T01, fmaf(rayy, P.T11, rnn * P.T21));
-        const float hx = fmaf(-s, rayx, P.ga) * rnn, hy = fmaf(-s, rayy, P.gb) * rnn;
-        float dpx = wx, dpy = wy;
+        const F nn = vfma(Px, Px, vfma(Py, Py, vsplat(u, 1.0f)));
+        const F rnn = vrsq(nn);
+        const F rayx = Px * rnn, rayy = Py * rnn;        // rayz = rnn
+        const F s = vfma(rayx, vsplat(u, P.ga), vfma(rayy, vsplat(u, P.gb), rnn * P.gc));
+        const F sc = vclamp(s, -1.0f + 1e-6f, 1.0f - 1e-6f);
+        const F rl = sin_halfpi(dlat) - sc;              // lm_optimizer.py:262,270-271
+        F wgt;
+        const F cost = huber(rl * rl, hk.inv_a2l, wgt);
+        wgt = wgt * cl;
+        acc[A_CL] = vfma(cost, cl, acc[A_CL]);
+        const F l0 = vfma(rayx, vsplat(u, P.T00), vfma(rayy, vsplat(u, P.T10), rnn * P.T20));
+        const F l1 = vfma(rayx, vsplat(u, P.T01), vfma(rayy, vsplat(u, P.T11), rnn * P.T21));
+        const F hx = vfma(-s, rayx, vsplat(u, P.ga)) * rnn, hy = vfma(-s, rayy, vsplat(u, P.gb)) * rnn;
+        // ds/df = h.(e w - 2 k1 (u,v)(uv.w)),  ds/dk1 = h.(-r2 (u,v))     (perspective_fields.py:255-272)
+        const F hw = vfma(hx, wx, hy * wy);
+        F l2 = hw;
+        [[maybe_unused]] F hu = vsplat(u, 0.f);
         if constexpr (DIST) {
-            const float m = k1x2 * uvw;
-            dpx = fmaf(e, wx, -m * u);
-            dpy = fmaf(e, wy, -m * v);
+            hu = vfma(hx, u, hy * v);
+            l2 = vfma(e, hw, -((uvw * k1x2) * hu));
         }
-        const float l2 = fmaf(hx, dpx, hy * dpy);
-        const float w0 = wgt * l0, w1 = wgt * l1, w2 = wgt * l2;
-        acc[A_G0 + 0] = fmaf(w0, rl, acc[A_G0 + 0]);
-        acc[A_G0 + 1] = fmaf(w1, rl, acc[A_G0 + 1]);
-        acc[A_G0 + 2] = fmaf(w2, rl, acc[A_G0 + 2]);
-        acc[A_H00 + 0] = fmaf(w0, l0, acc[A_H00 + 0]);
-        acc[A_H00 + 1] = fmaf(w0, l1, acc[A_H00 + 1]);
-        acc[A_H00 + 2] = fmaf(w0, l2, acc[A_H00 + 2]);
-        acc[A_H00 + 4] = fmaf(w1, l1, acc[A_H00 + 4]);
-        acc[A_H00 + 5] = fmaf(w1, l2, acc[A_H00 + 5]);
-        acc[A_H00 + 7] = fmaf(w2, l2, acc[A_H00 + 7]);
+        const F w0 = wgt * l0, w1 = wgt * l1, w2 = wgt * l2;
+        acc[A_G0 + 0] = vfma(w0, rl, acc[A_G0 + 0]);
+        acc[A_G0 + 1] = vfma(w1, rl, acc[A_G0 + 1]);
+        acc[A_G0 + 2] = vfma(w2, rl, acc[A_G0 + 2]);
+        acc[A_H00 + 0] = vfma(w0, l0, acc[A_H00 + 0]);
+        acc[A_H00 + 1] = vfma(w0, l1, acc[A_H00 + 1]);
+        acc[A_H00 + 2] = vfma(w0, l2, acc[A_H00 + 2]);
+        acc[A_H00 + 4] = vfma(w1, l1, acc[A_H00 + 4]);
+        acc[A_H00 + 5] = vfma(w1, l2, acc[A_H00 + 5]);
+        acc[A_H00 + 7] = vfma(w2, l2, acc[A_H00 + 7]);
         if constexpr (DIST) {
-            const float l3 = -fmaf(hx, u, hy * v) * r2;
-            const float w3 = wgt * l3;
-            acc[A_G0 + 3] = fmaf(w3, rl, acc[A_G0 + 3]);
-            acc[A_H00 + 3] = fmaf(w0, l3, acc[A_H00 + 3]);
-            acc[A_H00 + 6] = fmaf(w1, l3, acc[A_H00 + 6]);
-            acc[A_H00 + 8] = fmaf(w2, l3, acc[A_H00 + 8]);
-            acc[A_H00 + 9] = fmaf(w3, l3, acc[A_H00 + 9]);
+            const F l3 = -(hu * r2);
+            const F w3 = wgt * l3;
+            acc[A_G0 + 3] = vfma(w3, rl, acc[A_G0 + 3]);
+            acc[A_H00 + 3] = vfma(w0, l3, acc[A_H00 + 3]);
+            acc[A_H00 + 6] = vfma(w1, l3, acc[A_H00 + 6]);
+            acc[A_H00 + 8] = vfma(w2, l3, acc[A_H00 + 8]);
+            acc[A_H00 + 9] = vfma(w3, l3, acc[A_H00 + 9]);
         }
     }
 }
@@ -190,25 +225,34 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Per-lane tile of one loop iteration: VEC = 4 -> one float4 per plane, processed as two packed
+// pixel pairs; VEC = 1 -> one pixel, scalar math (odd widths / unaligned pointers).
 template <int VEC>
-struct Ld;
+struct Lane;
 template <>
-struct Ld<4> {
-    using T = float4;
-    static __device__ __forceinline__ T ld(const float* p, size_t unit) {
+struct Lane<4> {
+    using F = f2;
+    using V = float4;
+    static constexpr int kPairs = 2;
+    static __device__ __forceinline__ V ld(const float* p, size_t unit) {
         return *reinterpret_cast<const float4*>(p + unit * 4);
     }
-    static __device__ __forceinline__ float get(const T& v, int k) {
-        return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w));
+    static __device__ __forceinline__ F get(const V& v, int k) { return k == 0 ? f2{v.x, v.y} : f2{v.z, v.w}; }
+    static __device__ __forceinline__ V ones() { return make_float4(1.f, 1.f, 1.f, 1.f); }
+    static __device__ __forceinline__ F xcoord(int x, int k) {
+        const float x0 = (float)(x + 2 * k);
+        return f2{x0, x0 + 1.0f};
     }
-    static __device__ __forceinline__ T ones() { return make_float4(1.f, 1.f, 1.f, 1.f); }
 };
 template <>
-struct Ld<1> {
-    using T = float;
-    static __device__ __forceinline__ T ld(const float* p, size_t unit) { return p[unit]; }
-    static __device__ __forceinline__ float get(const T& v, int) { return v; }
-    static __device__ __forceinline__ T ones() { return 1.f; }
+struct Lane<1> {
+    using F = float;
+    using V = float;
+    static constexpr int kPairs = 1;
+    static __device__ __forceinline__ V ld(const float* p, size_t unit) { return p[unit]; }
+    static __device__ __forceinline__ F get(const V& v, int) { return v; }
+    static __device__ __forceinline__ V ones() { return 1.f; }
+    static __device__ __forceinline__ F xcoord(int x, int) { return (float)x; }
 };
 
 template <int MODEL, bool HAS_UP, bool HAS_UPC, bool HAS_LATC, int VEC>
@@ -232,9 +276,12 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs a) {
     const float* upc = HAS_UPC ? a.upc + (size_t)b * N : nullptr;
     const float* latc = HAS_LATC ? a.latc + (size_t)b * N : nullptr;
 
-    float acc[kNAcc];
+    using L = Lane<VEC>;
+    using F = typename L::F;
+    using V = typename L::V;
+    F acc[kNAcc];
 #pragma unroll
-    for (int i = 0; i < kNAcc; ++i) acc[i] = 0.f;
+    for (int i = 0; i < kNAcc; ++i) acc[i] = F(0.f);
 
     int unit = u0 + tid;
     int pix = unit * VEC;
@@ -242,22 +289,21 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs a) {
     int x = pix - y * a.W;
     const int step_pix = kBlock * VEC;
     const int dy = step_pix / a.W, dx = step_pix - dy * a.W;
-    using L = Ld<VEC>;
     for (; unit < u1; unit += kBlock) {
-        typename L::T vux, vuy, vcu = L::ones(), vcl = L::ones();
+        V vux, vuy, vcu = L::ones(), vcl = L::ones();
         if constexpr (HAS_UP) {
             vux = L::ld(upx, unit);
             vuy = L::ld(upy, unit);
         }
-        const typename L::T vlat = L::ld(lat, unit);
+        const V vlat = L::ld(lat, unit);
         if constexpr (HAS_UP && HAS_UPC) vcu = L::ld(upc, unit);
         if constexpr (HAS_LATC) vcl = L::ld(latc, unit);
         const float yf = (float)y;
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            pixel_accumulate<MODEL, HAS_UP>(P, hk, (float)(x + k), yf, HAS_UP ? L::get(vux, k) : 0.f,
-                                            HAS_UP ? L::get(vuy, k) : 0.f, L::get(vlat, k),
-                                            L::get(vcu, k), L::get(vcl, k), acc);
+        for (int k = 0; k < L::kPairs; ++k) {
+            pixel_accumulate<MODEL, HAS_UP, F>(P, hk, L::xcoord(x, k), yf, HAS_UP ? L::get(vux, k) : F(0.f),
+                                               HAS_UP ? L::get(vuy, k) : F(0.f), L::get(vlat, k), L::get(vcu, k),
+                                               L::get(vcl, k), acc);
         }
         x += dx;
         y += dy;
@@ -272,7 +318,7 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs a) {
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int i = 0; i < kNAcc; ++i) {
-        const float s = wave_sum(acc[i]);
+        const float s = wave_sum(hsum(acc[i]));
         if (lane == 0) red[wave][i] = s;
     }
     __syncthreads();
@@ -280,6 +326,8 @@ __global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs a) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < kBlock / 64; ++w) s += red[w][tid];
+        if (tid == A_CU) s *= hk.a2u;          // costs were accumulated in units of a^2
+        if (tid == A_CL) s *= hk.a2l;
         a.partials[((size_t)b * a.nchunks + chunk) * kNAcc + tid] = s;
     }
 }
