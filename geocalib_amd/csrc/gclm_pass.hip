@@ -35,6 +35,10 @@
 // this file, see the Makefile).
 #include "gclm_internal.h"
 
+#ifndef GCLM_NT_LOADS
+#define GCLM_NT_LOADS 1
+#endif
+
 namespace gclm {
 
 namespace {
@@ -235,7 +239,14 @@ struct Lane<4> {
     using V = float4;
     static constexpr int kPairs = 2;
     static __device__ __forceinline__ V ld(const float* p, size_t unit) {
+#if GCLM_NT_LOADS
+        // every byte is read exactly once per sweep: stream it past the caches (global_load ... nt)
+        typedef float v4 __attribute__((ext_vector_type(4)));
+        const v4 t = __builtin_nontemporal_load(reinterpret_cast<const v4*>(p + unit * 4));
+        return make_float4(t.x, t.y, t.z, t.w);
+#else
         return *reinterpret_cast<const float4*>(p + unit * 4);
+#endif
     }
     static __device__ __forceinline__ F get(const V& v, int k) { return k == 0 ? f2{v.x, v.y} : f2{v.z, v.w}; }
     static __device__ __forceinline__ V ones() { return make_float4(1.f, 1.f, 1.f, 1.f); }
