@@ -35,6 +35,9 @@
 // this file, see the Makefile).
 #include "gclm_internal.h"
 
+#ifndef GCLM_MIN_WAVES
+#define GCLM_MIN_WAVES 1
+#endif
 #ifndef GCLM_NT_LOADS
 #define GCLM_NT_LOADS 1
 #endif
@@ -267,7 +270,7 @@ struct Lane<1> {
 };
 
 template <int MODEL, bool HAS_UP, bool HAS_UPC, bool HAS_LATC, int VEC>
-__global__ __launch_bounds__(kBlock) void sweep_kernel(const SweepArgs a) {
+__global__ __launch_bounds__(kBlock, GCLM_MIN_WAVES) void sweep_kernel(const SweepArgs a) {
     if (a.skip_if_stopped && a.ctrl->stopped) return;   // batch-global early stop, no host sync
     const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
     const PBlock P = a.pb[b];                            // workgroup-uniform -> scalar loads
