@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--camera-model", default="pinhole", choices=["pinhole", "simple_radial"])
     ap.add_argument("--lm-steps", type=int, default=20)
+    ap.add_argument("--shared-group", type=int, default=0,
+                    help="frames per shared-intrinsics group (BASELINE configs[4]: 16); 0 = independent intrinsics. "
+                         "With N GPUs every group's frames are split over the ranks (one all-reduce per LM step)")
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="images for the CPU baseline (-1: auto, 0: skip)")
     ap.add_argument("--no-timing", action="store_true", help="skip the in-library HIP-event timing of the sweeps")
@@ -80,27 +83,38 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from geocalib_amd import LMOptimizer, _lib
-    from geocalib_amd.parallel import calibrate_sharded
+    from geocalib_amd.parallel import SharedIntrinsicsSplit, calibrate_sharded
+    from geocalib_amd.synth import synth_fields
 
     lib = _lib.load()
     B, H, W = args.batch, args.height, args.width
     n_total = B * world
-    up = torch.empty((B, 2, H, W), device=dev)
-    lat = torch.empty((B, 1, H, W), device=dev)
-    upc = torch.empty((B, H, W), device=dev)
-    latc = torch.empty((B, H, W), device=dev)
-    gt_cam = torch.empty((B, 8), device=dev)
-    gt_grav = torch.empty((B, 3), device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-    rc = lib.gclm_synth_fields(_lib.CAMERA_MODEL_IDS[args.camera_model], args.seed, rank * B, B, H, W, 0.02,
-                               up.data_ptr(), lat.data_ptr(), upc.data_ptr(), latc.data_ptr(),
-                               gt_cam.data_ptr(), gt_grav.data_ptr(), stream)
-    assert rc == 0, rc
-    data = {"up_field": up, "latitude_field": lat, "up_confidence": upc, "latitude_confidence": latc}
-    opt = LMOptimizer({"camera_model": args.camera_model, "num_steps": args.lm_steps, "early_stop": False}).eval()
+    gs = args.shared_group
+    conf = {"camera_model": args.camera_model, "num_steps": args.lm_steps, "early_stop": False}
+    if gs == 0:
+        # independent intrinsics: rank r owns the contiguous images [r*B, (r+1)*B)
+        data, gt_cam, gt_grav = synth_fields(args.camera_model, B, H, W, dev, seed=args.seed, first_index=rank * B)
+        opt = LMOptimizer(conf).eval()
 
-    def step():
-        return calibrate_sharded(opt, data, n_total)
+        def step():
+            return calibrate_sharded(opt, data, n_total)
+    else:
+        # shared intrinsics: n_total/gs groups; every rank holds gs/world frames of EVERY group
+        assert gs % world == 0 and B % (gs // world) == 0, "group size must be divisible by the number of GPUs"
+        fpg = gs // world                                   # frames per group on this rank
+        n_groups = B // fpg
+        data, gt_cam, gt_grav = synth_fields(args.camera_model, B, H, W, dev, seed=args.seed, first_index=rank * fpg,
+                                             group_size=gs, run=fpg, run_stride=gs)
+        opt = LMOptimizer({**conf, "shared_intrinsics": True, "group_size": gs}).eval()
+        if world == 1:
+            def step():
+                return opt(data)
+        else:
+            gof = torch.arange(B, device=dev, dtype=torch.int32) // fpg
+            split = SharedIntrinsicsSplit(opt, n_groups)
+
+            def step():
+                return split(data, gof)
 
     for _ in range(max(args.warmup, 1)):
         out = step()
@@ -144,12 +158,18 @@ def main():
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{1 if world == 1 else 2}]: batch={B}/GPU ({n_total} total) "
+            "config": {"workload": (f"BASELINE configs[{1 if world == 1 else 2}]: batch={B}/GPU ({n_total} total) "
+                                    if gs == 0 else
+                                    f"BASELINE configs[4] shape: shared intrinsics, {n_total // gs} groups x {gs} frames "
+                                    f"({B} frames/GPU), ") +
                                    f"synthetic {W}x{H} perspective fields, {args.camera_model}, "
                                    f"{args.lm_steps} LM iters + final/uncertainty sweep, early_stop=False",
+                       "shared_group": gs,
                        "camera_model": args.camera_model, "global_batch": n_total, "per_gpu_batch": B,
                        "height": H, "width": W, "lm_steps": args.lm_steps, "planes": PLANES,
-                       "parallelism": f"image-sharded x{world}, one all-gather of results" if world > 1 else "single GPU"},
+                       "parallelism": ("single GPU" if world == 1 else
+                                       f"image-sharded x{world}, one all-gather of results" if gs == 0 else
+                                       f"frames of every group split x{world}, one all-reduce per LM step")},
             "check": {"median_focal_rel_err_vs_gt": f_err, "median_gravity_abs_err_vs_gt": g_err},
         }
         if sweep_n:

@@ -59,6 +59,8 @@ _SIGNATURES = {
     "gclm_shared_finish": (C.c_int, [_P, _P, _P]),
     "gclm_synth_fields": (C.c_int, [C.c_int, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float,
                                     _P, _P, _P, _P, _P, _P, _P]),
+    "gclm_synth_fields_grouped": (C.c_int, [C.c_int, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float,
+                                            C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "gclm_set_timing": (C.c_int, [_P, C.c_int]),
     "gclm_last_pass_timing": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
 }

@@ -388,14 +388,23 @@ int gclm_shared_finish(gclm_handle* h, float* d_info_out, void* stream) {
     return 0;
 }
 
+int gclm_synth_fields_grouped(int camera_model, uint64_t seed, int64_t first_index, int B, int H, int W,
+                              float noise_sigma, int group_size, int run, int run_stride, float* d_up,
+                              float* d_lat, float* d_up_conf, float* d_lat_conf, float* d_gt_cam,
+                              float* d_gt_grav, void* stream) {
+    if (!d_up || !d_lat || B < 0 || H <= 0 || W <= 0 || group_size < 0 || run < 0) return -3;
+    if (camera_model != GCLM_PINHOLE && camera_model != GCLM_SIMPLE_RADIAL) return -2;
+    hipError_t e = launch_synth(camera_model, seed, first_index, B, H, W, noise_sigma, group_size, run, run_stride,
+                                d_up, d_lat, d_up_conf, d_lat_conf, d_gt_cam, d_gt_grav,
+                                static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : -10;
+}
+
 int gclm_synth_fields(int camera_model, uint64_t seed, int64_t first_index, int B, int H, int W,
                       float noise_sigma, float* d_up, float* d_lat, float* d_up_conf,
                       float* d_lat_conf, float* d_gt_cam, float* d_gt_grav, void* stream) {
-    if (!d_up || !d_lat || B < 0 || H <= 0 || W <= 0) return -3;
-    if (camera_model != GCLM_PINHOLE && camera_model != GCLM_SIMPLE_RADIAL) return -2;
-    hipError_t e = launch_synth(camera_model, seed, first_index, B, H, W, noise_sigma, d_up, d_lat, d_up_conf,
-                                d_lat_conf, d_gt_cam, d_gt_grav, static_cast<hipStream_t>(stream));
-    return e == hipSuccess ? 0 : -10;
+    return gclm_synth_fields_grouped(camera_model, seed, first_index, B, H, W, noise_sigma, 1, 0, 0, d_up, d_lat,
+                                     d_up_conf, d_lat_conf, d_gt_cam, d_gt_grav, stream);
 }
 
 }  // extern "C"

@@ -167,21 +167,26 @@ __device__ inline Plan make_plan(const gclm_config& cfg) {
     return p;
 }
 
-// Sum the workgroup partials of image b in a fixed order (double accumulate).
-__device__ inline void reduce_partials(const float* partials, int b, int nchunks, float (&acc)[kNAcc]) {
-    double d[kNAcc];
-#pragma unroll
-    for (int i = 0; i < kNAcc; ++i) d[i] = 0.0;
-    const float4* p = reinterpret_cast<const float4*>(partials + (size_t)b * nchunks * kNAcc);
-    for (int c = 0; c < nchunks; ++c) {
-#pragma unroll
-        for (int q = 0; q < kNAcc / 4; ++q) {
-            const float4 v = p[c * (kNAcc / 4) + q];
-            d[4 * q + 0] += v.x; d[4 * q + 1] += v.y; d[4 * q + 2] += v.z; d[4 * q + 3] += v.w;
-        }
+// Sum the workgroup partials of the images of this block in a fixed order (double accumulate).
+// Block-cooperative: 256 threads = 16 images x 16 accumulator slots; thread (image, slot) walks the
+// image's chunk records (64-byte rows: coalesced over the 16 slots), the per-image leader (slot 0)
+// then owns the 16 sums.  Returns true for leaders.  Must be called by every thread of the block.
+constexpr int kImgPerBlock = 16;
+__device__ inline bool coop_reduce_partials(const float* partials, int B, int nchunks, int& b, float (&acc)[kNAcc]) {
+    __shared__ float sacc[kImgPerBlock][kNAcc + 1];
+    const int li = threadIdx.x / kNAcc, slot = threadIdx.x % kNAcc;
+    b = blockIdx.x * kImgPerBlock + li;
+    if (b < B) {
+        double d = 0.0;
+        const float* p = partials + (size_t)b * nchunks * kNAcc + slot;
+        for (int c = 0; c < nchunks; ++c) d += p[(size_t)c * kNAcc];
+        sacc[li][slot] = (float)d;
     }
+    __syncthreads();
+    if (b >= B || slot != 0) return false;
 #pragma unroll
-    for (int i = 0; i < kNAcc; ++i) acc[i] = (float)d[i];
+    for (int i = 0; i < kNAcc; ++i) acc[i] = sacc[li][i];
+    return true;
 }
 
 // sum(c.mean(-1) for c in costs.values()) (lm_optimizer.py:584,610), float32
@@ -230,14 +235,13 @@ __global__ void init_kernel(SolveCtx c, const float* cam, const float* grav) {
 }
 
 // Independent intrinsics: one thread per image does reduce -> lambda -> damped solve -> update.
-__global__ void update_kernel(SolveCtx c, int step) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= c.B) return;
-    if (c.cfg.early_stop && c.ctrl->stopped) return;
+__global__ __launch_bounds__(kImgPerBlock * kNAcc) void update_kernel(SolveCtx c, int step) {
+    if (c.cfg.early_stop && c.ctrl->stopped) return;          // block-uniform
+    int b;
+    float acc[kNAcc];
+    if (!coop_reduce_partials(c.partials, c.B, c.nchunks, b, acc)) return;
     const gclm_config& cfg = c.cfg;
     State s = c.state[step & 1][b];
-    float acc[kNAcc];
-    reduce_partials(c.partials, b, c.nchunks, acc);
     const float invN = 1.0f / (float)((size_t)c.H * c.W);
     float cu, cl;
     const float total = total_cost(acc, invN, true, cu, cl);   // A_CU is 0 without an up field
@@ -311,14 +315,13 @@ __device__ inline void invert(int n, const float (&A)[4][4], double (&inv)[4][4]
 }
 
 // Final costs + estimate_uncertainty (lm_optimizer.py:632-642, 463-516) from the final sweep.
-__global__ void finalize_kernel(SolveCtx c, float* cam, float* grav, float* info) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= c.B) return;
+__global__ __launch_bounds__(kImgPerBlock * kNAcc) void finalize_kernel(SolveCtx c, float* cam, float* grav, float* info) {
+    int b;
+    float acc[kNAcc];
+    if (!coop_reduce_partials(c.partials, c.B, c.nchunks, b, acc)) return;
     const gclm_config& cfg = c.cfg;
     const int sel = c.ctrl->final_sel;
     State s = c.state[sel][b];
-    float acc[kNAcc];
-    reduce_partials(c.partials, b, c.nchunks, acc);
     const float invN = 1.0f / (float)((size_t)c.H * c.W);
     float cu, cl;
     const float total = total_cost(acc, invN, true, cu, cl);
@@ -386,13 +389,12 @@ __global__ void stop_at_kernel(SolveCtx c, float* info) {
 // be all-reduced across devices when a group's frames are sharded (BASELINE config 5).
 
 // per frame: reduce partials -> frame_sys, costs / allclose bookkeeping
-__global__ void shared_frame_kernel(SolveCtx c, int step) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= c.B) return;
+__global__ __launch_bounds__(kImgPerBlock * kNAcc) void shared_frame_kernel(SolveCtx c, int step) {
     if (c.cfg.early_stop && c.ctrl->stopped) return;
-    State s = c.state[step & 1][b];
+    int b;
     float acc[kNAcc];
-    reduce_partials(c.partials, b, c.nchunks, acc);
+    if (!coop_reduce_partials(c.partials, c.B, c.nchunks, b, acc)) return;
+    State s = c.state[step & 1][b];
     const float invN = 1.0f / (float)((size_t)c.H * c.W);
     float cu, cl;
     const float total = total_cost(acc, invN, true, cu, cl);
@@ -523,11 +525,10 @@ __global__ void pblock_from_params_kernel(SolveCtx c, const float* cam, const fl
     out[b] = p;
 }
 
-__global__ void system_out_kernel(SolveCtx c, float* cost, float* grad, float* hess) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= c.B) return;
+__global__ __launch_bounds__(kImgPerBlock * kNAcc) void system_out_kernel(SolveCtx c, float* cost, float* grad, float* hess) {
+    int b;
     float acc[kNAcc];
-    reduce_partials(c.partials, b, c.nchunks, acc);
+    if (!coop_reduce_partials(c.partials, c.B, c.nchunks, b, acc)) return;
     const float invN = 1.0f / (float)((size_t)c.H * c.W);
     cost[b * 2] = acc[A_CU] * invN;
     cost[b * 2 + 1] = acc[A_CL] * invN;
@@ -551,15 +552,18 @@ __device__ inline uint64_t mix64(uint64_t z) {   // splitmix64 finaliser
 __device__ inline float u01(uint64_t h) { return ((float)(h >> 40) + 0.5f) * (1.0f / 16777216.0f); }
 
 struct GT { float fx, k1; V3 g; };
-__device__ inline GT synth_gt(int model, uint64_t seed, int64_t index, int H) {
+// gravity is keyed by the image index, the intrinsics by `intr_index` (= image index, or the
+// group index when frames of a group share one camera)
+__device__ inline GT synth_gt(int model, uint64_t seed, int64_t index, int64_t intr_index, int H) {
     const uint64_t base = mix64(seed ^ mix64((uint64_t)index * 0xD1342543DE82EF95ull + 1));
+    const uint64_t ibase = mix64(seed ^ mix64((uint64_t)intr_index * 0xD1342543DE82EF95ull + 1));
     const float d2r = kPi / 180.f;
     const float roll = (u01(mix64(base + 1)) * 90.f - 45.f) * d2r;
     const float pitch = (u01(mix64(base + 2)) * 90.f - 45.f) * d2r;
-    const float vfov = (20.f + u01(mix64(base + 3)) * 70.f) * d2r;
+    const float vfov = (20.f + u01(mix64(ibase + 3)) * 70.f) * d2r;
     GT t;
     t.fx = (float)H * 0.5f / tanf(vfov * 0.5f);
-    t.k1 = model == GCLM_PINHOLE ? 0.f : -0.3f + 0.4f * u01(mix64(base + 4));
+    t.k1 = model == GCLM_PINHOLE ? 0.f : -0.3f + 0.4f * u01(mix64(ibase + 4));
     t.g = from_rp(roll, pitch);
     return t;
 }
@@ -567,10 +571,13 @@ __device__ inline GT synth_gt(int model, uint64_t seed, int64_t index, int H) {
 // One thread per pixel: ground-truth perspective field (perspective_fields.py:278) + Gaussian
 // noise, up re-normalised, latitude clamped, confidences ~ U(0,1)  (SURVEY.md 8d).
 __global__ void synth_kernel(int model, uint64_t seed, int64_t first, int B, int H, int W, float sigma,
+                             int group_size, int run, int run_stride,
                              float* up, float* lat, float* upc, float* latc, float* gt_cam, float* gt_grav) {
     const int b = blockIdx.y;
     const size_t N = (size_t)H * W;
-    const GT t = synth_gt(model, seed, first + b, H);
+    // global image index of local image b: contiguous, or runs of `run` images every `run_stride`
+    const int64_t gidx = first + (run > 0 ? (int64_t)(b / run) * run_stride + (b % run) : b);
+    const GT t = synth_gt(model, seed, gidx, group_size > 1 ? gidx / group_size : gidx, H);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (gt_cam) {
             float* cm = gt_cam + (size_t)b * 8;
@@ -591,7 +598,7 @@ __global__ void synth_kernel(int model, uint64_t seed, int64_t first, int B, int
         const float rn = rsqrtf(Px * Px + Py * Py + 1.f);
         float s = (Px * t.g.x + Py * t.g.y + t.g.z) * rn;
         s = fminf(fmaxf(s, -1.f + 1e-6f), 1.f - 1e-6f);
-        const uint64_t h = mix64(mix64(seed ^ 0xA5A5A5A5ull) + (uint64_t)(first + b) * 0x9E3779B97F4A7C15ull + i * 4);
+        const uint64_t h = mix64(mix64(seed ^ 0xA5A5A5A5ull) + (uint64_t)gidx * 0x9E3779B97F4A7C15ull + i * 4);
         // Box-Muller, two pairs
         const float a1 = sqrtf(-2.f * logf(u01(mix64(h + 1)))), p1 = 2.f * kPi * u01(mix64(h + 2));
         const float a2 = sqrtf(-2.f * logf(u01(mix64(h + 3)))), p2 = 2.f * kPi * u01(mix64(h + 4));
@@ -615,13 +622,16 @@ inline dim3 grid1(int n) { return dim3((n + 127) / 128); }
 }  // namespace
 
 #define GCLM_L(kernel, n, s, ...) hipLaunchKernelGGL(kernel, grid1(n), dim3(128), 0, s, __VA_ARGS__)
+// cooperative-reduce kernels: 16 images per 256-thread block
+#define GCLM_LR(kernel, n, s, ...) \
+    hipLaunchKernelGGL(kernel, dim3(((n) + kImgPerBlock - 1) / kImgPerBlock), dim3(kImgPerBlock * kNAcc), 0, s, __VA_ARGS__)
 
 hipError_t launch_init(const SolveCtx& c, const float* d_cam, const float* d_grav, hipStream_t s) {
     GCLM_L(init_kernel, c.B, s, c, d_cam, d_grav);
     return hipGetLastError();
 }
 hipError_t launch_update(const SolveCtx& c, int step, hipStream_t s) {
-    GCLM_L(update_kernel, c.B, s, c, step);
+    GCLM_LR(update_kernel, c.B, s, c, step);
     return hipGetLastError();
 }
 hipError_t launch_decide(const SolveCtx& c, int step, hipStream_t s) {
@@ -633,12 +643,12 @@ hipError_t launch_prep_final(const SolveCtx& c, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_finalize(const SolveCtx& c, float* d_cam, float* d_grav, float* d_info, hipStream_t s) {
-    GCLM_L(finalize_kernel, c.B, s, c, d_cam, d_grav, d_info);
+    GCLM_LR(finalize_kernel, c.B, s, c, d_cam, d_grav, d_info);
     GCLM_L(stop_at_kernel, c.B, s, c, d_info);
     return hipGetLastError();
 }
 hipError_t launch_shared_reduce(const SolveCtx& c, int step, float* d_group_partials, hipStream_t s) {
-    if (c.B > 0) GCLM_L(shared_frame_kernel, c.B, s, c, step);
+    if (c.B > 0) GCLM_LR(shared_frame_kernel, c.B, s, c, step);
     GCLM_L(shared_group_kernel, c.n_groups, s, c, step, d_group_partials);
     return hipGetLastError();
 }
@@ -647,7 +657,7 @@ hipError_t launch_shared_apply(const SolveCtx& c, int step, const float* d_group
     return hipGetLastError();
 }
 hipError_t launch_system_out(const SolveCtx& c, float* d_cost, float* d_grad, float* d_hess, hipStream_t s) {
-    GCLM_L(system_out_kernel, c.B, s, c, d_cost, d_grad, d_hess);
+    GCLM_LR(system_out_kernel, c.B, s, c, d_cost, d_grad, d_hess);
     return hipGetLastError();
 }
 hipError_t launch_pblock_from_params(const SolveCtx& c, const float* d_cam, const float* d_grav, int as_rpf,
@@ -656,13 +666,13 @@ hipError_t launch_pblock_from_params(const SolveCtx& c, const float* d_cam, cons
     return hipGetLastError();
 }
 hipError_t launch_synth(int camera_model, uint64_t seed, int64_t first_index, int B, int H, int W, float sigma,
-                        float* up, float* lat, float* upc, float* latc, float* gt_cam, float* gt_grav,
+                        int group_size, int run, int run_stride, float* up, float* lat, float* upc, float* latc, float* gt_cam, float* gt_grav,
                         hipStream_t s) {
     if (B <= 0) return hipSuccess;
     const size_t N = (size_t)H * W;
     const int bx = (int)((N + 255) / 256 < 64 ? (N + 255) / 256 : 64);
     hipLaunchKernelGGL(synth_kernel, dim3(bx, B), dim3(256), 0, s, camera_model, seed, first_index, B, H, W,
-                       sigma, up, lat, upc, latc, gt_cam, gt_grav);
+                       sigma, group_size, run, run_stride, up, lat, upc, latc, gt_cam, gt_grav);
     return hipGetLastError();
 }
 

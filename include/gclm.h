@@ -155,6 +155,14 @@ int gclm_synth_fields(int camera_model, uint64_t seed, int64_t first_index, int 
                       float noise_sigma, float* d_up, float* d_lat, float* d_up_conf,
                       float* d_lat_conf, float* d_gt_cam, float* d_gt_grav, void* stream);
 
+/* Same generator with shared-intrinsics structure and strided index runs (multi-GPU frame split):
+ * intrinsics (focal, k1) are keyed by global_index / group_size (group_size <= 1: per image), and local
+ * image b maps to global index first_index + (b / run) * run_stride + b % run (run = 0: contiguous). */
+int gclm_synth_fields_grouped(int camera_model, uint64_t seed, int64_t first_index, int B, int H, int W,
+                              float noise_sigma, int group_size, int run, int run_stride, float* d_up,
+                              float* d_lat, float* d_up_conf, float* d_lat_conf, float* d_gt_cam,
+                              float* d_gt_grav, void* stream);
+
 /* Timing helper: when enabled, every sweep launch is bracketed by HIP events on the solve's stream;
  * gclm_last_pass_timing waits for the recorded launches, returns their count and summed duration
  * since the previous read, and resets the record.  Returns <0 if timing was not enabled. */

@@ -3,18 +3,15 @@ import ctypes as C, sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from geocalib_amd import LMOptimizer, _lib
+from geocalib_amd.synth import synth_fields
 lib = _lib.load(); dev = torch.device("cuda:0")
 H, W = 480, 640
 models = sys.argv[1].split(",") if len(sys.argv) > 1 else ["pinhole", "simple_radial"]
 sizes = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [64, 256, 1024]
 for model in models:
   for B in sizes:
-    up = torch.empty((B, 2, H, W), device=dev); lat = torch.empty((B, 1, H, W), device=dev)
-    upc = torch.empty((B, H, W), device=dev); latc = torch.empty((B, H, W), device=dev)
-    gtc = torch.empty((B, 8), device=dev)
-    lib.gclm_synth_fields(_lib.CAMERA_MODEL_IDS[model], 1, 0, B, H, W, 0.02, up.data_ptr(), lat.data_ptr(), upc.data_ptr(), latc.data_ptr(), gtc.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+    d, gtc, _ = synth_fields(model, B, H, W, dev, seed=1)
     opt = LMOptimizer({"camera_model": model, "num_steps": 20, "early_stop": False}).eval()
-    d = {"up_field": up, "latitude_field": lat, "up_confidence": upc, "latitude_confidence": latc}
     out = opt(d); torch.cuda.synchronize()
     h = opt._handle(dev); lib.gclm_set_timing(h.ptr, 1)
     t = time.perf_counter(); n = 5
@@ -24,4 +21,4 @@ for model in models:
     avg = ms.value / k.value
     ferr = (out["camera"]._data[:, 3] / gtc[:, 3] - 1).abs().median().item()
     print(f"{model:14s} B={B:5d}: sweep {avg*1e3:8.1f} us = {B*H*W*20/avg/1e9:6.2f} TB/s | solve {dt*1e3:7.2f} ms = {B/dt:8.0f} img/s | f err {ferr:.1e}", flush=True)
-    del up, lat, upc, latc
+    del d

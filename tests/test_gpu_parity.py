@@ -241,20 +241,11 @@ def test_split_api_single_rank_equals_solve(dev, setname):
 
 # ------------------------------------------------------------------ properties at the BASELINE size
 
-def synth_device(model, B, H, W, dev, seed=11, first=0):
-    from geocalib_amd import _lib
-    up = torch.empty((B, 2, H, W), device=dev)
-    lat = torch.empty((B, 1, H, W), device=dev)
-    upc = torch.empty((B, H, W), device=dev)
-    latc = torch.empty((B, H, W), device=dev)
-    gtc = torch.empty((B, 8), device=dev)
-    gtg = torch.empty((B, 3), device=dev)
-    rc = _lib.load().gclm_synth_fields(_lib.CAMERA_MODEL_IDS[model], seed, first, B, H, W, 0.02, up.data_ptr(),
-                                       lat.data_ptr(), upc.data_ptr(), latc.data_ptr(), gtc.data_ptr(), gtg.data_ptr(),
-                                       torch.cuda.current_stream().cuda_stream)
-    assert rc == 0
+def synth_device(model, B, H, W, dev, seed=11, first=0, **kw):
+    from geocalib_amd.synth import synth_fields
+    out = synth_fields(model, B, H, W, dev, seed=seed, first_index=first, **kw)
     torch.cuda.synchronize()
-    return {"up_field": up, "latitude_field": lat, "up_confidence": upc, "latitude_confidence": latc}, gtc, gtg
+    return out
 
 
 def test_synth_generator_is_index_keyed(dev):
@@ -265,6 +256,16 @@ def test_synth_generator_is_index_keyed(dev):
     assert torch.equal(ca[3:], cb) and torch.equal(ga[3:], gb)
     assert torch.allclose(a["up_field"].norm(dim=1), torch.ones(6, 48, 64, device=dev), atol=1e-5)
     assert a["latitude_field"].abs().max() <= np.pi / 2 and 0 <= a["up_confidence"].min() and a["up_confidence"].max() <= 1
+    # grouped / strided variant (multi-GPU frame split): frames of a group share the intrinsics and a
+    # rank's strided runs equal the corresponding images of the contiguous generation
+    g, cg, gg = synth_device("simple_radial", 8, 48, 64, dev, group_size=4)
+    assert torch.equal(cg[:4, 2], cg[0, 2].expand(4)) and torch.equal(cg[4:, 6], cg[4, 6].expand(4)) and cg[0, 2] != cg[4, 2]
+    assert not torch.equal(gg[0], gg[1])
+    r1, c1, g1 = synth_device("simple_radial", 4, 48, 64, dev, first=2, group_size=4, run=2, run_stride=4)
+    sel = [2, 3, 6, 7]
+    for k in g:
+        assert torch.equal(g[k][sel], r1[k]), k
+    assert torch.equal(cg[sel], c1) and torch.equal(gg[sel], g1)
 
 
 @pytest.mark.parametrize("model", HIP_MODELS)
@@ -309,3 +310,51 @@ def test_full_size_batch_properties(dev, oracle, model):
     sample = {k: v[idx].cpu().numpy() for k, v in data.items()}
     ref = oracle.solve(sample, {"camera_model": model, "num_steps": 20, "early_stop": False}, precision="f32")
     compare_result({k: v[idx] for k, v in a.items()}, ref, TOL, f"B1024/{model}")
+
+
+@pytest.mark.parametrize("model", HIP_MODELS)
+def test_split_protocol_two_virtual_ranks(dev, model):
+    """BASELINE configs[4] protocol on ONE device: the frames of every group are dealt to two handles
+    ("ranks"); per LM step both reduce their local Schur partials, the partial buffers are summed (what the
+    RCCL all-reduce does), both apply.  Must equal the single-handle shared-intrinsics solve."""
+    from geocalib_amd import LMOptimizer, _lib, get_trivial_estimation
+    lib = _lib.load()
+    G, gs, H, W = 6, 8, 48, 64
+    data, gtc, gtg = synth_device(model, G * gs, H, W, dev, seed=3, group_size=gs)
+    conf = {"camera_model": model, "num_steps": 12, "early_stop": False, "shared_intrinsics": True, "group_size": gs}
+    single = to_np(LMOptimizer(conf).eval()(data))
+    frames = torch.arange(G * gs, device=dev)
+    ranks = []
+    for r in range(2):
+        sel = frames[(frames % gs) // (gs // 2) == r]                 # rank r: frames [r*gs/2, (r+1)*gs/2) of each group
+        local = {k: v[sel].contiguous() for k, v in data.items()}
+        opt = LMOptimizer(conf).eval()
+        cam0, grav0 = get_trivial_estimation(local, opt.camera_model)
+        opt.setup_optimization_and_priors(local, shared_intrinsics=True)
+        up, lat, upc, latc, (B, _, _) = opt._fields(local)
+        h = opt._handle(dev)
+        st = dict(opt=opt, h=h, sel=sel, cam=cam0._data.clone(), grav=grav0._data.clone(), keep=(up, lat, upc, latc),
+                  gof=(torch.arange(B, device=dev, dtype=torch.int32) // (gs // 2)).contiguous(),
+                  part=torch.zeros((G, _lib.SHARED_PARTIAL_STRIDE), device=dev), info=torch.empty((B, _lib.INFO_STRIDE), device=dev))
+        _lib.check(lib.gclm_shared_begin(h.ptr, up.data_ptr(), lat.data_ptr(), upc.data_ptr(), latc.data_ptr(), B, H, W,
+                                         st["cam"].data_ptr(), st["grav"].data_ptr(), st["gof"].data_ptr(), G, None), h.ptr)
+        ranks.append(st)
+    for step in range(conf["num_steps"]):
+        for st in ranks:
+            _lib.check(lib.gclm_shared_reduce(st["h"].ptr, step, st["part"].data_ptr(), None), st["h"].ptr)
+        total = ranks[0]["part"] + ranks[1]["part"]                    # the all-reduce
+        for st in ranks:
+            st["part"].copy_(total)
+            _lib.check(lib.gclm_shared_apply(st["h"].ptr, step, st["part"].data_ptr(), None), st["h"].ptr)
+    for st in ranks:
+        _lib.check(lib.gclm_shared_finish(st["h"].ptr, st["info"].data_ptr(), None), st["h"].ptr)
+    torch.cuda.synchronize()
+    for st in ranks:
+        sel = st["sel"].cpu().numpy()
+        assert np.abs(st["cam"].cpu().numpy()[:, 2:4] / single["camera"][sel, 2:4] - 1).max() < 2e-6
+        assert np.abs(st["cam"].cpu().numpy()[:, 6] - single["camera"][sel, 6]).max() < 2e-6
+        assert np.abs(st["grav"].cpu().numpy() - single["gravity"][sel]).max() < 2e-6
+        assert np.allclose(st["info"][:, _lib.INFO["final_cost"]].cpu().numpy(), single["final_cost"][sel], rtol=1e-5)
+    # one focal per group
+    f = single["camera"][:, 3].reshape(G, gs)
+    assert np.abs(f / f[:, :1] - 1).max() < 1e-6
