@@ -52,6 +52,7 @@ _SIGNATURES = {
     "gclm_last_error": (C.c_char_p, [_P]),
     "gclm_workspace_bytes": (C.c_size_t, [_P]),
     "gclm_solve": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "gclm_calibrate": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P]),
     "gclm_system": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P]),
     "gclm_shared_begin": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_int, _P]),
     "gclm_shared_reduce": (C.c_int, [_P, C.c_int, _P, _P]),

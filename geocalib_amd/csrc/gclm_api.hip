@@ -258,12 +258,11 @@ int gclm_last_pass_timing(gclm_handle* h, int* n_launches, float* total_ms) {
     return 0;
 }
 
-int gclm_solve(gclm_handle* h, const float* d_up, const float* d_lat, const float* d_up_conf,
-               const float* d_lat_conf, int B, int H, int W, float* d_cam_io, float* d_grav_io,
-               float* d_info_out, void* stream) {
-    if (!h) return -1;
+static int run_solve(gclm_handle* h, const float* d_up, const float* d_lat, const float* d_up_conf,
+                     const float* d_lat_conf, int B, int H, int W, const InitArgs& ia, float* d_cam_out,
+                     float* d_grav_out, float* d_info_out, void* stream) {
     if (int rc = check_shapes(h, d_lat, B, H, W)) return rc;
-    if (!d_cam_io || !d_grav_io || !d_info_out) return fail(h, -3, "gclm_solve: null output pointer");
+    if (!d_cam_out || !d_grav_out || !d_info_out) return fail(h, -3, "null output pointer");
     if (B == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     GCLM_HIP(h, hipSetDevice(h->device));
@@ -277,7 +276,7 @@ int gclm_solve(gclm_handle* h, const float* d_up, const float* d_lat, const floa
     h->sh.active = false;
 
     GCLM_HIP(h, hipMemsetAsync(d_info_out, 0, sizeof(float) * GCLM_INFO_STRIDE * (size_t)B, s));
-    GCLM_HIP(h, launch_init(c, d_cam_io, d_grav_io, s));
+    GCLM_HIP(h, launch_init(c, ia, s));
     const bool es = h->cfg.early_stop != 0;
     for (int step = 0; step < h->cfg.num_steps; ++step) {
         const SweepArgs a = sweep_args(h, d_up, d_lat, d_up_conf, d_lat_conf, c.pb[step & 1], geo, es);
@@ -293,8 +292,37 @@ int gclm_solve(gclm_handle* h, const float* d_up, const float* d_lat, const floa
     GCLM_HIP(h, launch_prep_final(c, s));
     const SweepArgs a = sweep_args(h, d_up, d_lat, d_up_conf, d_lat_conf, c.pb_final, geo, false);
     if (int rc = timed_sweep(h, a, s)) return rc;
-    GCLM_HIP(h, launch_finalize(c, d_cam_io, d_grav_io, d_info_out, s));
+    GCLM_HIP(h, launch_finalize(c, d_cam_out, d_grav_out, d_info_out, s));
     return 0;
+}
+
+int gclm_solve(gclm_handle* h, const float* d_up, const float* d_lat, const float* d_up_conf,
+               const float* d_lat_conf, int B, int H, int W, float* d_cam_io, float* d_grav_io,
+               float* d_info_out, void* stream) {
+    if (!h) return -1;
+    InitArgs ia{};
+    ia.cam = d_cam_io;
+    ia.grav = d_grav_io;
+    if (!d_cam_io || !d_grav_io) return fail(h, -3, "gclm_solve: null camera / gravity pointer");
+    return run_solve(h, d_up, d_lat, d_up_conf, d_lat_conf, B, H, W, ia, d_cam_io, d_grav_io, d_info_out, stream);
+}
+
+int gclm_calibrate(gclm_handle* h, const float* d_up, const float* d_lat, const float* d_up_conf,
+                   const float* d_lat_conf, int B, int H, int W, const float* d_scales,
+                   const float* d_prior_focal, const float* d_prior_gravity, const float* d_prior_dist,
+                   int prior_dist_cols, float* d_cam_out, float* d_grav_out, float* d_info_out, void* stream) {
+    if (!h) return -1;
+    if (d_prior_dist && (prior_dist_cols < 1 || prior_dist_cols > 2)) return fail(h, -3, "gclm_calibrate: prior_dist_cols must be 1 or 2");
+    // the free-parameter flags must agree with the priors (setup_optimization_and_priors, :204-221)
+    if ((d_prior_focal != nullptr) == (h->cfg.estimate_focal != 0) || (d_prior_gravity != nullptr) == (h->cfg.estimate_gravity != 0))
+        return fail(h, -2, "gclm_calibrate: estimate_focal / estimate_gravity disagree with the priors passed");
+    InitArgs ia{};
+    ia.scales = d_scales;
+    ia.prior_focal = d_prior_focal;
+    ia.prior_gravity = d_prior_gravity;
+    ia.prior_dist = d_prior_dist;
+    ia.prior_dist_cols = prior_dist_cols;
+    return run_solve(h, d_up, d_lat, d_up_conf, d_lat_conf, B, H, W, ia, d_cam_out, d_grav_out, d_info_out, stream);
 }
 
 int gclm_system(gclm_handle* h, const float* d_up, const float* d_lat, const float* d_up_conf,
@@ -342,7 +370,10 @@ int gclm_shared_begin(gclm_handle* h, const float* d_up, const float* d_lat, con
     h->sh.up = d_up; h->sh.lat = d_lat; h->sh.upc = d_up_conf; h->sh.latc = d_lat_conf;
     h->sh.cam_io = d_cam_io; h->sh.grav_io = d_grav_io;
     h->sh.active = true;
-    GCLM_HIP(h, launch_init(c, d_cam_io, d_grav_io, s));
+    InitArgs ia{};
+    ia.cam = d_cam_io;
+    ia.grav = d_grav_io;
+    GCLM_HIP(h, launch_init(c, ia, s));
     return 0;
 }
 

@@ -82,7 +82,16 @@ struct SolveCtx {
     float* frame_sys;           // (B, kNAcc) reduced per-frame system (shared mode / system())
     Ctrl* ctrl;
 };
-hipError_t launch_init(const SolveCtx& c, const float* d_cam, const float* d_grav, hipStream_t s);
+struct InitArgs {              // initial estimate: explicit (cam, grav) or trivial estimation from the priors
+    const float* cam;           // (B,8) or nullptr -> get_trivial_estimation on the device
+    const float* grav;          // (B,3)
+    const float* scales;        // (2,) or nullptr
+    const float* prior_focal;   // (B,) or nullptr
+    const float* prior_gravity; // (B,3) or nullptr
+    const float* prior_dist;    // (B, prior_dist_cols) or nullptr
+    int prior_dist_cols;
+};
+hipError_t launch_init(const SolveCtx& c, const InitArgs& ia, hipStream_t s);
 hipError_t launch_update(const SolveCtx& c, int step, hipStream_t s);
 hipError_t launch_decide(const SolveCtx& c, int step, hipStream_t s);
 hipError_t launch_prep_final(const SolveCtx& c, hipStream_t s);

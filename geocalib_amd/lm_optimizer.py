@@ -70,6 +70,13 @@ class _Handle:
             pass
 
 
+def _unit_gravity(data: torch.Tensor) -> Gravity:
+    """Wrap device results that are unit vectors already (skips the constructor's re-normalisation kernels)."""
+    g = Gravity.__new__(Gravity)
+    g._data = data
+    return g
+
+
 def _dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
     if not t.is_cuda:
         raise RuntimeError(f"geocalib_amd: `{name}` must live on a HIP device (got {t.device}); "
@@ -201,7 +208,7 @@ class LMOptimizer(nn.Module):
                                         B, H, W, cam.data_ptr(), grav.data_ptr(), info.data_ptr(), stream)
         _lib.check(rc, h.ptr, "gclm_solve")
         self._last_raw = (cam, grav, info)     # packed device results (parallel.calibrate_sharded)
-        return camera_opt.__class__(cam), Gravity(grav), self._unpack_info(info, up is not None)
+        return camera_opt.__class__(cam), _unit_gravity(grav), self._unpack_info(info, up is not None)
 
     def _unpack_info(self, info: torch.Tensor, has_up: bool) -> Dict[str, torch.Tensor]:
         I = _lib.INFO
@@ -228,10 +235,46 @@ class LMOptimizer(nn.Module):
     def forward(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         """Run the LM optimisation (reference: lm_optimizer.py:646-664)."""
         with torch.no_grad():
-            camera_init, gravity_init = get_trivial_estimation(data, self.camera_model)
+            data["latitude_field"]            # KeyError like get_trivial_estimation (lm_optimizer.py:31)
             self.setup_optimization_and_priors(data, shared_intrinsics=self.shared_intrinsics)
-            camera_opt, gravity_opt, infos = self.optimize(data, camera_init, gravity_init)
+            camera_opt, gravity_opt, infos = self.calibrate_fields(data)
         return {"camera": camera_opt, "gravity": gravity_opt, **infos}
+
+    def calibrate_fields(self, data: Dict[str, torch.Tensor]) -> Tuple[BaseCamera, Gravity, Dict[str, torch.Tensor]]:
+        """get_trivial_estimation + optimize in ONE C call (gclm_calibrate): the initial estimate is built
+        on the device from (H, W) and the priors, so no host-side tensor op precedes the kernels."""
+        up, lat, upc, latc, (B, H, W) = self._fields(data)
+        device = lat.device
+        h = self._handle(device)
+
+        def prior(key, shape):
+            if key not in data:
+                return None
+            t = data[key]
+            t = t._data if hasattr(t, "_data") else torch.as_tensor(t)
+            t = t.detach().to(device=device, dtype=torch.float32).contiguous()
+            assert t.numel() == int(torch.tensor(shape).prod()), (key, t.shape, shape)
+            return t
+
+        scales = prior("scales", (2,))
+        pf = prior("prior_focal", (B,))
+        pg = prior("prior_gravity", (B, 3))
+        nd = self.camera_model.num_dist_params() if self.camera_has_distortion else 0
+        pd = None
+        if "prior_dist" in data and nd:
+            pd = data["prior_dist"].detach().to(device=device, dtype=torch.float32).contiguous()
+            nd = pd.shape[-1] if pd.dim() > 1 else 1
+        cam = torch.empty((B, 8), dtype=torch.float32, device=device)
+        grav = torch.empty((B, 3), dtype=torch.float32, device=device)
+        info = torch.empty((B, _lib.INFO_STRIDE), dtype=torch.float32, device=device)
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            P = self._ptr
+            rc = _lib.load().gclm_calibrate(h.ptr, P(up), P(lat), P(upc), P(latc), B, H, W, P(scales), P(pf), P(pg),
+                                            P(pd), nd, cam.data_ptr(), grav.data_ptr(), info.data_ptr(), stream)
+        _lib.check(rc, h.ptr, "gclm_calibrate")
+        self._last_raw = (cam, grav, info)
+        return self.camera_model(cam), _unit_gravity(grav), self._unpack_info(info, up is not None)
 
     # ------------------------------------------------------------------ kernel-level entry (tests, tools)
     def system(self, data: Dict[str, torch.Tensor], camera: BaseCamera, gravity: Gravity,

@@ -120,6 +120,21 @@ int gclm_solve(gclm_handle* h, const float* d_up, const float* d_lat, const floa
                float* d_info_out, void* stream);
 
 /*
+ * LMOptimizer.forward (lm_optimizer.py:646-664): get_trivial_estimation (:20-58; roll = pitch = 0,
+ * f = 0.7 max(h, w) through the vfov round trip, principal point at the centre, priors substituted) evaluated
+ * on the device, then gclm_solve.  No host-side tensor op is needed before the call.
+ *   d_scales         (2,)   or NULL   data["scales"]:  fx = f * scales[0] / scales[1]   (camera.py:89-90)
+ *   d_prior_focal    (B,)   or NULL   data["prior_focal"]   (requires cfg.estimate_focal == 0)
+ *   d_prior_gravity  (B,3)  or NULL   data["prior_gravity"] (requires cfg.estimate_gravity == 0)
+ *   d_prior_dist     (B,prior_dist_cols) or NULL   data["prior_dist"]
+ *   d_cam_out (B,8), d_grav_out (B,3), d_info_out (B,GCLM_INFO_STRIDE): outputs
+ */
+int gclm_calibrate(gclm_handle* h, const float* d_up, const float* d_lat, const float* d_up_conf,
+                   const float* d_lat_conf, int B, int H, int W, const float* d_scales,
+                   const float* d_prior_focal, const float* d_prior_gravity, const float* d_prior_dist,
+                   int prior_dist_cols, float* d_cam_out, float* d_grav_out, float* d_info_out, void* stream);
+
+/*
  * One fused sweep at fixed parameters: calculate_residuals + calculate_costs + setup_system
  * (lm_optimizer.py:248-315,387-461).  as_rpf selects the (roll, pitch, focal) parametrisation used
  * by estimate_uncertainty (:481-483).  Outputs, per image: d_cost (B,2) mean up / latitude Huber cost,
