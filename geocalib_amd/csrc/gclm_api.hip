@@ -58,8 +58,10 @@ int fail(gclm_handle* h, int code, const char* fmt, ...) {
     } while (0)
 
 const char* validate(const gclm_config& c) {
-    if (c.camera_model != GCLM_PINHOLE && c.camera_model != GCLM_SIMPLE_RADIAL)
-        return "camera_model: only pinhole (0) and simple_radial (1) are implemented by the HIP path";
+    if (c.camera_model < GCLM_PINHOLE || c.camera_model > GCLM_SIMPLE_DIVISIONAL)
+        return "camera_model: unknown (0 pinhole, 1 simple_radial, 2 radial, 3 simple_divisional)";
+    if (c.shared_intrinsics && c.camera_model == GCLM_RADIAL)
+        return "shared_intrinsics with the radial model (3 shared intrinsics) is not implemented by the HIP path";
     if (c.num_steps < 0 || c.num_steps > GCLM_MAX_STEPS) return "num_steps out of range [0, GCLM_MAX_STEPS]";
     if (!(c.up_loss_fn_scale > 0.f) || !(c.lat_loss_fn_scale > 0.f)) return "loss scales must be > 0";
     if (c.group_size < 0) return "group_size must be >= 0";
@@ -67,7 +69,7 @@ const char* validate(const gclm_config& c) {
         return "shared_intrinsics requires gravity and focal to be estimated (lm_optimizer.py:350-383)";
     if (c.shared_intrinsics && c.camera_model != GCLM_PINHOLE && !c.estimate_dist)
         return "shared_intrinsics with a distortion prior is not supported";
-    const int n = 2 * (c.estimate_gravity != 0) + (c.estimate_focal != 0) + (c.camera_model != GCLM_PINHOLE);
+    const int n = 2 * (c.estimate_gravity != 0) + (c.estimate_focal != 0) + num_dist_params(c.camera_model);
     if (n == 0) return "No parameters to optimize";
     return nullptr;
 }
@@ -82,8 +84,8 @@ int ensure_workspace(gclm_handle* h, int B, int nchunks, int G) {
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_state0 = take(sizeof(State) * B), o_state1 = take(sizeof(State) * B);
     const size_t o_pb0 = take(sizeof(PBlock) * B), o_pb1 = take(sizeof(PBlock) * B), o_pbf = take(sizeof(PBlock) * B);
-    const size_t o_part = take(sizeof(float) * kNAcc * (size_t)B * nchunks);
-    const size_t o_fsys = take(sizeof(float) * kNAcc * (size_t)B);
+    const size_t o_part = take(sizeof(float) * kNAccMax * (size_t)B * nchunks);
+    const size_t o_fsys = take(sizeof(float) * kNAccMax * (size_t)B);
     const size_t o_gp = take(sizeof(float) * GCLM_SHARED_PARTIAL_STRIDE * (size_t)(G > 0 ? G : 1));
     const size_t o_ctrl = take(sizeof(Ctrl));
     if (off > h->ws_bytes) {
@@ -424,7 +426,7 @@ int gclm_synth_fields_grouped(int camera_model, uint64_t seed, int64_t first_ind
                               float* d_lat, float* d_up_conf, float* d_lat_conf, float* d_gt_cam,
                               float* d_gt_grav, void* stream) {
     if (!d_up || !d_lat || B < 0 || H <= 0 || W <= 0 || group_size < 0 || run < 0) return -3;
-    if (camera_model != GCLM_PINHOLE && camera_model != GCLM_SIMPLE_RADIAL) return -2;
+    if (camera_model < GCLM_PINHOLE || camera_model > GCLM_SIMPLE_DIVISIONAL) return -2;
     hipError_t e = launch_synth(camera_model, seed, first_index, B, H, W, noise_sigma, group_size, run, run_stride,
                                 d_up, d_lat, d_up_conf, d_lat_conf, d_gt_cam, d_gt_grav,
                                 static_cast<hipStream_t>(stream));

@@ -89,9 +89,11 @@ __device__ inline void update_focal(State& s, float delta, bool as_log) {
 }
 
 // SimpleRadial.update_dist (camera.py:599-604); slot 7 shadows k1 for one-parameter models
-__device__ inline void update_dist(State& s, float delta, float lo, float hi) {
-    s.k1 = fminf(fmaxf(s.k1 + delta, lo), hi);
-    s.k2 = fminf(fmaxf(s.k2 + delta, lo), hi);
+__device__ inline void update_dist(State& s, int camera_model, float d1, float d2) {
+    // range (-0.7, 0.7), simple_divisional (-3, 3)  (camera.py:599, 700, 817)
+    const float hi = camera_model == GCLM_SIMPLE_DIVISIONAL ? 3.0f : 0.7f;
+    s.k1 = fminf(fmaxf(s.k1 + d1, -hi), hi);
+    s.k2 = fminf(fmaxf(s.k2 + (camera_model == GCLM_RADIAL ? d2 : d1), -hi), hi);
 }
 
 __device__ inline void build_pblock(const State& s, bool spherical, bool log_focal, PBlock& p) {
@@ -103,13 +105,14 @@ __device__ inline void build_pblock(const State& s, bool spherical, bool log_foc
     p.T00 = T[0][0]; p.T01 = T[0][1]; p.T10 = T[1][0]; p.T11 = T[1][1]; p.T20 = T[2][0]; p.T21 = T[2][1];
     p.wfx = log_focal ? 1.0f : 1.0f / s.fx;
     p.wfy = log_focal ? 1.0f : 1.0f / s.fy;
+    p.k2 = s.k2; p.pad0 = p.pad1 = p.pad2 = 0.f;
 }
 
 // ---------------------------------------------------------------- small dense algebra
 
 // In-place Cholesky solve of an n x n SPD system (fp32 like torch.linalg.cholesky on fp32).
 template <int MAXN>
-__device__ inline bool chol_solve(int n, float (&A)[MAXN][MAXN], float (&b)[MAXN]) {
+__device__ inline bool chol_solve(int n, float (&A)[MAXN][MAXN], float* b) {
     for (int j = 0; j < n; ++j) {
         float s = A[j][j];
         for (int k = 0; k < j; ++k) s -= A[j][k] * A[j][k];
@@ -135,31 +138,27 @@ __device__ inline bool chol_solve(int n, float (&A)[MAXN][MAXN], float (&b)[MAXN
     return true;
 }
 
-// Symmetric 4x4 system out of an accumulator record (full column set d1,d2,f,k1).
-__device__ inline void unpack_system(const float* acc, float (&Hm)[4][4], float (&G)[4]) {
-    const float* h = acc + A_H00;
-    Hm[0][0] = h[0]; Hm[0][1] = h[1]; Hm[0][2] = h[2]; Hm[0][3] = h[3];
-    Hm[1][1] = h[4]; Hm[1][2] = h[5]; Hm[1][3] = h[6];
-    Hm[2][2] = h[7]; Hm[2][3] = h[8]; Hm[3][3] = h[9];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        G[i] = acc[A_G0 + i];
-        for (int j = 0; j < i; ++j) Hm[i][j] = Hm[j][i];
+// Symmetric PM x PM system (PM = 4 or 5 full columns d1,d2,f,k1[,k2]) out of an accumulator record.
+__device__ inline void unpack_system(const float* acc, int pm, float (&Hm)[kMaxP][kMaxP], float (&G)[kMaxP]) {
+    for (int i = 0; i < kMaxP; ++i) {
+        G[i] = i < pm ? acc[A_G0 + i] : 0.f;
+        for (int j = 0; j < kMaxP; ++j) Hm[i][j] = 0.f;
     }
+    for (int i = 0; i < pm; ++i)
+        for (int j = i; j < pm; ++j) Hm[i][j] = Hm[j][i] = acc[acc_h(pm, i, j)];
 }
 
 // Column plan of calculate_gradient_and_hessian (lm_optimizer.py:335-344)
 struct Plan {
-    int n, cols[4];
+    int n, cols[kMaxP];
     int focal_dim, dist_dim;   // lm_optimizer.py:223-235 (python indices into delta)
 };
 __device__ inline Plan make_plan(const gclm_config& cfg) {
     Plan p;
     p.n = 0;
-    const bool has_dist = cfg.camera_model != GCLM_PINHOLE;
     if (cfg.estimate_gravity) { p.cols[p.n++] = 0; p.cols[p.n++] = 1; }
     if (cfg.estimate_focal) p.cols[p.n++] = 2;
-    if (has_dist) p.cols[p.n++] = 3;
+    for (int k = 0; k < num_dist_params(cfg.camera_model); ++k) p.cols[p.n++] = 3 + k;
     p.focal_dim = cfg.estimate_focal ? (cfg.estimate_gravity ? 2 : 0) : -1;
     p.dist_dim = p.focal_dim + 1;          // reproduces the prior_focal + distortion overlap (quirk)
     return p;
@@ -191,7 +190,7 @@ __device__ inline void cost_bookkeeping(const gclm_config& cfg, Ctrl* ctrl, int 
 // One LM step of one image from its reduced accumulator record: lambda rule + allclose bookkeeping,
 // damped normal equations over the estimated columns, manifold / focal / distortion update, next
 // parameter block.  (update_kernel body; also run by the last workgroup of an image in the fused sweep.)
-__device__ inline void update_image(const SolveCtx& c, int step, int b, const float (&acc)[kNAcc]) {
+__device__ inline void update_image(const SolveCtx& c, int step, int b, const float (&acc)[kNAccMax]) {
     const gclm_config& cfg = c.cfg;
     State s = c.state[step & 1][b];
     const float invN = 1.0f / (float)((size_t)c.H * c.W);
@@ -201,17 +200,17 @@ __device__ inline void update_image(const SolveCtx& c, int step, int b, const fl
     cost_bookkeeping(cfg, c.ctrl, step, total, s, !cfg.fix_lambda);
 
     // damped normal equations over the estimated columns (lm_optimizer.py:109-137)
-    float Hf[4][4], Gf[4];
-    unpack_system(acc, Hf, Gf);
+    float Hf[kMaxP][kMaxP], Gf[kMaxP];
+    unpack_system(acc, acc_pm(cfg.camera_model), Hf, Gf);
     const Plan pl = make_plan(cfg);
-    float A[4][4], d[4] = {0.f, 0.f, 0.f, 0.f};
+    float A[kMaxP][kMaxP], d[kMaxP + 1] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int i = 0; i < pl.n; ++i) {
         d[i] = Gf[pl.cols[i]];
         for (int j = 0; j < pl.n; ++j) A[i][j] = Hf[pl.cols[i]][pl.cols[j]];
     }
     for (int i = 0; i < pl.n; ++i) A[i][i] += fmaxf(A[i][i] * s.lambda, 1e-6f);
-    if (!chol_solve<4>(pl.n, A, d)) {
-        d[0] = d[1] = d[2] = d[3] = 0.f;     // zero step for THIS image (reference: whole batch)
+    if (!chol_solve<kMaxP>(pl.n, A, d)) {
+        for (int i = 0; i <= kMaxP; ++i) d[i] = 0.f;   // zero step for THIS image (reference: whole batch)
         s.fails += 1.f;
     }
     // update_estimate (lm_optimizer.py:518-549)
@@ -219,7 +218,8 @@ __device__ inline void update_image(const SolveCtx& c, int step, int b, const fl
     const V3 g = grav_update({s.gx, s.gy, s.gz}, d0, d1, cfg.use_spherical_manifold != 0);
     s.gx = g.x; s.gy = g.y; s.gz = g.z;
     update_focal(s, cfg.estimate_focal ? d[pl.focal_dim] : 0.f, cfg.use_log_focal != 0);
-    if (cfg.camera_model != GCLM_PINHOLE && cfg.estimate_dist) update_dist(s, d[pl.dist_dim], -0.7f, 0.7f);
+    if (cfg.camera_model != GCLM_PINHOLE && cfg.estimate_dist)
+        update_dist(s, cfg.camera_model, d[pl.dist_dim], d[pl.dist_dim + 1]);
 
     c.state[(step + 1) & 1][b] = s;
     PBlock p;

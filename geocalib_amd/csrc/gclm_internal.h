@@ -10,8 +10,10 @@
 namespace gclm {
 
 constexpr int kBlock = 256;        // 4 waves of 64
-constexpr int kNAcc = 16;          // floats per partial record (see enum Acc)
-constexpr int kPBlockFloats = 16;
+constexpr int kNAcc = 16;          // floats per partial record for models with <= 4 parameters (see enum Acc)
+constexpr int kNAccMax = 24;       // ... and for the 5-parameter `radial` model (2 + 5 + 15 = 22, padded)
+constexpr int kPBlockFloats = 20;
+constexpr int kMaxP = GCLM_MAX_PARAMS;
 constexpr int kStateFloats = 16;
 
 // Partial / accumulator record of one sweep over (part of) an image.
@@ -19,6 +21,16 @@ constexpr int kStateFloats = 16;
 //   [2..5] G = sum w J^T r over columns (d1, d2, f, k1)
 //   [6..15] upper triangle of sum w J^T J: 00 01 02 03 11 12 13 22 23 33
 enum Acc { A_CU = 0, A_CL = 1, A_G0 = 2, A_H00 = 6 };
+// General layout for PM = 4 (record of 16) or PM = 5 (record of 24) full columns (d1, d2, f, k1[, k2]):
+//   [2 .. 2+PM) gradient, then the upper triangle of the Hessian row-major.
+__host__ __device__ constexpr int acc_pm(int camera_model) { return camera_model == GCLM_RADIAL ? 5 : 4; }
+__host__ __device__ constexpr int acc_floats(int camera_model) { return camera_model == GCLM_RADIAL ? kNAccMax : kNAcc; }
+__host__ __device__ constexpr int acc_h(int pm, int i, int j) {   // i <= j
+    return 2 + pm + i * pm - (i * (i - 1)) / 2 + (j - i);
+}
+__host__ __device__ constexpr int num_dist_params(int camera_model) {
+    return camera_model == GCLM_PINHOLE ? 0 : (camera_model == GCLM_RADIAL ? 2 : 1);
+}
 
 // Per-image constants consumed by the sweep (written by the update kernels).
 struct __attribute__((aligned(16))) PBlock {
@@ -26,7 +38,8 @@ struct __attribute__((aligned(16))) PBlock {
     float ga, gb, gc, k1;            // gravity (a,b,c), distortion
     float T00, T01, T10, T11;        // tangent basis T[i][k] (3x2): SphericalManifold.J_plus(g) in the
     float T20, T21, wfx, wfy;        //   loop, Gravity.J_rp() for uncertainty; (wfx,wfy): focal column
-};                                   //   scale (1,1) for log-focal, (1/fx,1/fy) otherwise
+    float k2, pad0, pad1, pad2;      //   scale (1,1) for log-focal, (1/fx,1/fy) otherwise; k2: radial model
+};
 static_assert(sizeof(PBlock) == kPBlockFloats * 4, "PBlock layout");
 
 // Per-image optimiser state (double-buffered across steps).
@@ -52,7 +65,7 @@ struct SweepArgs {
     const float* latc;      // (B,H,W) or nullptr
     const PBlock* pb;       // (B)
     const Ctrl* ctrl;       // nullptr: never skip
-    float* partials;        // (B, nchunks, kNAcc)
+    float* partials;        // (B, nchunks, acc_floats(model))
     int B, H, W;
     int nchunks;            // blocks per image
     int units_per_block;    // float4 groups (or pixels in the scalar path) per block
@@ -79,7 +92,7 @@ struct SolveCtx {
     PBlock* pb[2];
     PBlock* pb_final;
     float* partials;
-    float* frame_sys;           // (B, kNAcc) reduced per-frame system (shared mode / system())
+    float* frame_sys;           // (B, acc_floats(model)) reduced per-frame system (shared mode)
     Ctrl* ctrl;
 };
 struct InitArgs {              // initial estimate: explicit (cam, grav) or trivial estimation from the priors

@@ -4,35 +4,42 @@
 // the 3..5 input planes:
 //   * the perspective-field prediction (up vector, sin latitude)       perspective_fields.py:47-81,185-211
 //   * residuals and scaled-Huber costs / weights x confidences         lm_optimizer.py:248-315
-//   * the analytic Jacobian rows wrt (d1, d2, focal[, k1])             perspective_fields.py:84-182,214-275
+//   * the analytic Jacobian rows wrt (d1, d2, focal[, k1[, k2]])       perspective_fields.py:84-182,214-275
 //   * the reductions sum w J^T r and sum w J^T J                       lm_optimizer.py:317-385
 // The reference materialises (B,N,2,P) Jacobians and ~100x the algorithmic bytes; here nothing
 // per-pixel ever leaves registers.
 //
-// Closed form used (checked against the oracle's literal matrix chains):
+// Closed form (SURVEY.md section 8-A generalised to any radial model; checked against the oracle's
+// literal matrix chains).  Every camera model of camera.py is radial: distort(p) = p s(r2),
+// undistort(p) = p tau(r2).  With s1 = ds/dr2, s2 = d2s/dr2^2, tau1 = dtau/dr2:
 //   u=(x-cx)/fx, v=(y-cy)/fy, r2=u^2+v^2
-//   UP   p=(a-c u, b-c v); d=1+k1 r2; t=u px+v py; q=d p+2 k1 t (u,v)  (pinhole: q=p); up=q/|q|
+//   UP   p=(a-c u, b-c v); t=u px+v py; q = M p, M = s I + 2 s1 uv uv^T (symmetric); up=q/|q|
 //        d(up)/d(theta) = n (n . dq/dtheta)/|q| with n=(-up_y, up_x)  [I - up up^T = n n^T in 2-D]
 //        => the 2 x P up-Jacobian is rank one: J_up = n s^T,  J^T J = s s^T,  J^T r = s (n . r);
-//        dq/dtheta = M dp/dtheta + ..., M = d I + 2 k1 uv uv^T symmetric => s_k = (M nq).dp/dtheta_k
-//   LAT  e=1-k1 r2; P=e (u,v); ray=(P,1)/sqrt(|P|^2+1); s=ray.g; r_lat=sin(lat_data)-clamp(s)
-//        ds/d(delta_k)=ray.T[:,k];  ds/df=h.(e w-2 k1 (u,v)(uv.w));  ds/dk1=h.(-r2 (u,v)),
+//        with nq = n/|q| and m = M nq:   s_k  = m . dp/ddelta_k,
+//        s_f  = -c (m.w) + 2 s1 [(nq.p)(uv.w) + (nq.uv)(p.w)] + t [jd (nq.w) + 4 s2 (uv.w)(nq.uv)],
+//        s_kj = (ds/dk_j)(nq.p) + 2 (ds1/dk_j) t (nq.uv)            (jd = 2 s1: diagonal of d(off)/duv)
+//   LAT  P=tau (u,v); ray=(P,1)/sqrt(|P|^2+1); s=ray.g; r_lat=sin(lat_data)-clamp(s)
+//        ds/d(delta_k)=ray.T[:,k];  ds/df = tau (h.w) + 2 tau1 (uv.w)(h.uv);  ds/dk_j = (dtau/dk_j)(h.uv),
 //        h=(g_xy-s ray_xy)/sqrt(|P|^2+1),  w=(-u wfx,-v wfy)
+//   pinhole: s = tau = 1.  simple_radial: s = 1+k1 r2, tau = 1-k1 r2.  radial: s = 1+k1 r2+k2 r4,
+//   tau = 1-k1 r2+(3k1^2-k2) r4.  simple_divisional: s = (1-sqrt(1-4k r2))/(2k r2), tau = 1/(1+k r2)
+//   with the reference's own guards (camera.py:829-940).
 //
 // Mapping to the machine: grid = (chunks per image, B); a 256-thread workgroup (4 waves of 64)
-// streams a contiguous run of float4 groups of one image with fully coalesced 16 B/lane loads
-// (1 KiB per wave-instruction per plane); the 64-byte parameter block of the image is read with
-// scalar loads (workgroup-uniform -> SGPRs); 16 accumulators per lane are reduced with wave64
-// shuffles, then across the 4 waves through LDS, and ONE 64-byte partial record per workgroup is
-// written (no atomics: bit-reproducible).  No MFMA: the contraction is N x P -> P x P with P <= 4.
+// streams a contiguous run of float4 groups of one image with fully coalesced, non-temporal
+// 16 B/lane loads (1 KiB per wave-instruction per plane); the 80-byte parameter block of the image
+// is read with scalar loads (workgroup-uniform -> SGPRs); 16 (24 for `radial`) accumulators per lane
+// are reduced with wave64 shuffles, then across the 4 waves through LDS, and ONE partial record per
+// workgroup is written (no atomics: bit-reproducible).  No MFMA: the contraction is N x P -> P x P,
+// P <= 5.
 //
 // Arithmetic: PMC counters (profiles/r01_pmc_sq_*) show the sweep is VALU-issue-bound as soon as
-// it approaches ~6 TB/s (scalar fp32 FMA sustains ~1 wave64 instruction / 3 cycles / SIMD), so the
-// float4 path computes PIXEL PAIRS in packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32:
-// two pixels per instruction) -- written explicitly on a 2-wide vector type so the pairs live in
-// adjacent registers straight out of the dwordx4 loads (LLVM's SLP vectoriser finds some of these
-// pairs on its own but pays for them with register shuffles and 2x the VGPRs; it is switched off for
-// this file, see the Makefile).
+// it approaches ~6 TB/s, so the float4 path computes PIXEL PAIRS in packed fp32 (v_pk_fma_f32 /
+// v_pk_mul_f32 / v_pk_add_f32: two pixels per instruction) -- written explicitly on a 2-wide vector
+// type so the pairs live in adjacent registers straight out of the dwordx4 loads (LLVM's SLP
+// vectoriser finds some of these pairs on its own but pays for them with register shuffles and 2x
+// the VGPRs; it is switched off for this file, see the Makefile).
 #include "gclm_internal.h"
 
 #ifndef GCLM_MIN_WAVES
@@ -54,6 +61,10 @@ __device__ __forceinline__ float vfma(float a, float b, float c) { return fmaf(a
 __device__ __forceinline__ f2 vfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ float vrsq(float a) { return __frsqrt_rn(a); }
 __device__ __forceinline__ f2 vrsq(f2 a) { return f2{__frsqrt_rn(a.x), __frsqrt_rn(a.y)}; }
+__device__ __forceinline__ float vrcp(float a) { return __frcp_rn(a); }
+__device__ __forceinline__ f2 vrcp(f2 a) { return f2{__frcp_rn(a.x), __frcp_rn(a.y)}; }
+__device__ __forceinline__ float vsqrt(float a) { return __fsqrt_rn(a); }
+__device__ __forceinline__ f2 vsqrt(f2 a) { return f2{__fsqrt_rn(a.x), __fsqrt_rn(a.y)}; }
 __device__ __forceinline__ float vmax(float a, float b) { return fmaxf(a, b); }
 __device__ __forceinline__ f2 vmax(f2 a, f2 b) { return f2{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
 __device__ __forceinline__ float vclamp(float a, float lo, float hi) { return fminf(fmaxf(a, lo), hi); }
@@ -65,6 +76,12 @@ __device__ __forceinline__ float vsel_le1(float y, float a, float b) { return y 
 __device__ __forceinline__ f2 vsel_le1(f2 y, f2 a, f2 b) {
     return f2{y.x <= 1.0f ? a.x : b.x, y.y <= 1.0f ? a.y : b.y};
 }
+// denominator guard of the reference: x.masked_fill(x == 0, 1e6)
+__device__ __forceinline__ float vguard(float a) { return a == 0.f ? 1e6f : a; }
+__device__ __forceinline__ f2 vguard(f2 a) { return f2{a.x == 0.f ? 1e6f : a.x, a.y == 0.f ? 1e6f : a.y}; }
+// select(d == 0, a, b)
+__device__ __forceinline__ float vsel_eq0(float d, float a, float b) { return d == 0.f ? a : b; }
+__device__ __forceinline__ f2 vsel_eq0(f2 d, f2 a, f2 b) { return f2{d.x == 0.f ? a.x : b.x, d.y == 0.f ? a.y : b.y}; }
 __device__ __forceinline__ float vsplat(float, float s) { return s; }
 __device__ __forceinline__ f2 vsplat(f2, float s) { return f2{s, s}; }
 __device__ __forceinline__ float hsum(float a) { return a; }
@@ -99,8 +116,107 @@ struct HuberK {
     float inv_a2u, a2u, inv_a2l, a2l;
 };
 
+// Radial-model terms at r2 (see the header comment).  Only the members a model needs are computed; for
+// pinhole / simple_radial everything else folds away at compile time.
+template <typename F>
+struct Radial {
+    F s, s1x2, jd, s2x4;          // s, 2 s1, diagonal of d(off)/duv (= 2 s1), 4 s2
+    F ds[2], ds1x2[2];            // ds/dk_j, 2 d(s1)/dk_j
+    F tau, tau1x2, dtau[2];       // undistortion scale, 2 tau1, dtau/dk_j
+};
+
+template <int MODEL, typename F>
+__device__ __forceinline__ void radial_terms(const PBlock& P, F r2, Radial<F>& R) {
+    const F one = vsplat(r2, 1.0f), zero = vsplat(r2, 0.f);
+    R.s = R.tau = one;
+    R.s1x2 = R.jd = R.s2x4 = R.tau1x2 = zero;
+    R.ds[0] = R.ds[1] = R.ds1x2[0] = R.ds1x2[1] = R.dtau[0] = R.dtau[1] = zero;
+    if constexpr (MODEL == GCLM_SIMPLE_RADIAL) {                 // camera.py:611-660
+        R.s = vfma(r2, vsplat(r2, P.k1), one);
+        R.s1x2 = R.jd = vsplat(r2, 2.0f * P.k1);
+        R.ds[0] = r2;
+        R.ds1x2[0] = vsplat(r2, 2.0f);
+        R.tau = vfma(r2, vsplat(r2, -P.k1), one);
+        R.tau1x2 = vsplat(r2, -2.0f * P.k1);
+        R.dtau[0] = -r2;
+    } else if constexpr (MODEL == GCLM_RADIAL) {                 // camera.py:712-786
+        const F r4 = r2 * r2;
+        R.s = vfma(r4, vsplat(r2, P.k2), vfma(r2, vsplat(r2, P.k1), one));
+        R.s1x2 = R.jd = vfma(r2, vsplat(r2, 4.0f * P.k2), vsplat(r2, 2.0f * P.k1));
+        R.s2x4 = vsplat(r2, 8.0f * P.k2);
+        R.ds[0] = r2;  R.ds1x2[0] = vsplat(r2, 2.0f);
+        R.ds[1] = r4;  R.ds1x2[1] = 4.0f * r2;
+        const float b1 = -P.k1, b2 = 3.0f * P.k1 * P.k1 - P.k2;
+        R.tau = vfma(r4, vsplat(r2, b2), vfma(r2, vsplat(r2, b1), one));
+        R.tau1x2 = vfma(r2, vsplat(r2, 4.0f * b2), vsplat(r2, 2.0f * b1));
+        R.dtau[0] = vfma(r4, vsplat(r2, 6.0f * P.k1), -r2);
+        R.dtau[1] = -r4;
+    } else if constexpr (MODEL == GCLM_SIMPLE_DIVISIONAL) {      // camera.py:829-940, guards as there
+        const float k = P.k1;
+        const F tt = vfma(r2, vsplat(r2, -4.0f * k), one);           // 1 - 4 k r2
+        const F den = r2 * (2.0f * k);
+        R.s = vsel_eq0(den, one, (one - vsqrt(vmax(tt, zero))) * vrcp(vguard(den)));
+        const F t0 = vmax(tt, vsplat(r2, 1e-6f));
+        const F t1 = vsqrt(t0), it1 = vrcp(t1);
+        const F omt = one - t1;
+        const F r4 = r2 * r2;
+        {   // J_distort scale2pts (:843-851): off = uv (4 d2 - (1-t1) d1)/(d1 d2), d1 = 2 t1 r2, d2 = k r4
+            const F d1 = t1 * (2.0f * r2), d2 = r4 * k;
+            R.s1x2 = vfma(d2, vsplat(r2, 4.0f), -(omt * d1)) * vrcp(vguard(d1 * d2));
+        }
+        {   // J_up_projection_offset wrt uv (:912-940): diagonal jd and the uv uv^T coefficient
+            R.jd = 4.0f * vrcp(vguard(2.0f * r2 * t1)) - omt * vrcp(vguard(r4 * k));
+            F pc = -16.0f * vrcp(vguard(4.0f * t1 * r4));
+            pc = pc + (32.0f * k) * vrcp(vguard(4.0f * r2 * t0 * t1));
+            pc = pc - 4.0f * vrcp(vguard(r4 * t1));
+            pc = pc + 4.0f * omt * vrcp(vguard(r4 * r2 * k));
+            R.s2x4 = pc;
+        }
+        {   // J_distort scale2dist (:853-857)
+            const F d1 = t1 * (2.0f * k), d2 = r2 * (2.0f * k * k);
+            R.ds[0] = vfma(d2, vsplat(r2, 2.0f), -(omt * d1)) * vrcp(vguard(d1 * d2));
+        }
+        {   // J_up_projection_offset wrt dist (:898-911)
+            F J = 16.0f * vrcp(vguard(4.0f * t0 * t1));
+            J = J - 2.0f * vrcp(vguard(r2 * t1 * k));
+            const F rk = r2 * k;
+            J = J + omt * vrcp(vguard(rk * rk));
+            R.ds1x2[0] = J;
+        }
+        const F den2 = vfma(r2, vsplat(r2, k), one);                  // 1 + k r2
+        R.tau = vrcp(vguard(den2));
+        R.tau1x2 = (-2.0f * k) * R.tau * R.tau;                        // :878-883
+        R.dtau[0] = -r2 * vrcp(vguard(den2 * den2));                   // :875-877
+        (void)it1;
+    }
+}
+
+template <int MODEL>
+struct Layout {
+    static constexpr int PM = acc_pm(MODEL);            // full columns of the record (4, radial 5)
+    static constexpr int ND = num_dist_params(MODEL);   // distortion parameters of the model
+    static constexpr int PN = 3 + ND;                   // columns this model accumulates
+    static constexpr int NACC = acc_floats(MODEL);
+};
+
+// acc += wgt * J^T r and wgt * J^T J (upper triangle) for a rank-one Jacobian row set s[0..PN)
+template <int MODEL, typename F>
+__device__ __forceinline__ void accumulate(F (&acc)[Layout<MODEL>::NACC], const F (&s)[Layout<MODEL>::PN], F wgt, F r) {
+    constexpr int PM = Layout<MODEL>::PM, PN = Layout<MODEL>::PN;
+#pragma unroll
+    for (int i = 0; i < PN; ++i) {
+        const F wi = wgt * s[i];
+        acc[A_G0 + i] = vfma(wi, r, acc[A_G0 + i]);
+#pragma unroll
+        for (int j = i; j < PN; ++j) acc[acc_h(PM, i, j)] = vfma(wi, s[j], acc[acc_h(PM, i, j)]);
+    }
+}
+
+// Hand-scheduled form of the same math for the two BASELINE models (pinhole, simple_radial): identical
+// operations to pixel_accumulate<> below with the model terms substituted, written out so that the
+// compiler reaches 96 / 128 VGPRs (5 / 4 waves per SIMD) without spills or dependency stalls.
 template <int MODEL, bool HAS_UP, typename F>
-__device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& hk, F xf, float yf, F dux, F duy,
+__device__ __forceinline__ void pixel_accumulate_fast(const PBlock& P, const HuberK& hk, F xf, float yf, F dux, F duy,
                                                  F dlat, F cu, F cl, F (&acc)[kNAcc]) {
     constexpr bool DIST = MODEL != GCLM_PINHOLE;
     const F u = (xf - P.cx) * P.ifx;
@@ -226,6 +342,108 @@ __device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& 
     }
 }
 
+template <int MODEL, bool HAS_UP, typename F>
+__device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& hk, F xf, float yf, F dux, F duy,
+                                                 F dlat, F cu, F cl, F (&acc)[Layout<MODEL>::NACC]) {
+    constexpr bool DIST = MODEL != GCLM_PINHOLE;
+    constexpr int ND = Layout<MODEL>::ND, PN = Layout<MODEL>::PN;
+    const F u = (xf - P.cx) * P.ifx;
+    const float v = (yf - P.cy) * P.ify;                 // one image row per tile: v is lane-scalar
+    const F r2 = vfma(u, u, vsplat(u, v * v));
+    const F wx = u * (-P.wfx);                           // d(uv)/d(focal parameter) = (wx, wy)
+    const float wy = -v * P.wfy;
+    const F uvw = vfma(u, wx, vsplat(u, v * wy));
+    Radial<F> R;
+    radial_terms<MODEL>(P, r2, R);
+
+    if constexpr (HAS_UP) {
+        const F px = vfma(u, vsplat(u, -P.gc), vsplat(u, P.ga));
+        const float py = fmaf(-P.gc, v, P.gb);
+        F qx = px, qy = vsplat(u, py), t = vsplat(u, 0.f);
+        if constexpr (DIST) {
+            t = vfma(u, px, vsplat(u, v * py));
+            const F kt = R.s1x2 * t;
+            qx = vfma(R.s, px, kt * u);
+            qy = vfma(R.s, vsplat(u, py), kt * v);
+        }
+        const F n2 = vmax(vfma(qx, qx, qy * qy), vsplat(u, 1e-24f));
+        const F rn = vrsq(n2);
+        const F ux = qx * rn, uy = qy * rn;              // predicted up vector
+        const F rx = dux - ux, ry = duy - uy;            // residual (lm_optimizer.py:266)
+        const F x2 = vfma(rx, rx, ry * ry);
+        F wgt;
+        const F cost = huber(x2, hk.inv_a2u, wgt);
+        wgt = wgt * cu;
+        acc[A_CU] = vfma(cost, cu, acc[A_CU]);
+        // rank-one Jacobian: s_k = (M nq) . dp/dtheta_k, nq = n/|q|, n = (-uy, ux);  rho = n . r
+        const F nx = -uy * rn, ny = ux * rn;
+        const F nuv = vfma(nx, u, ny * v);
+        const F nw = vfma(nx, wx, ny * wy);
+        F mx = nx, my = ny, muv = nuv, mw = nw;
+        if constexpr (DIST) {
+            const F c2 = R.s1x2 * nuv;
+            mx = vfma(R.s, nx, c2 * u);
+            my = vfma(R.s, ny, c2 * v);
+            muv = vfma(mx, u, my * v);
+            mw = vfma(mx, wx, my * wy);
+        }
+        F s[PN];
+        // dp/ddelta_k = (T0k - u T2k, T1k - v T2k)  =>  s_k = m.T[0:2,k] - (m.uv) T2k
+        s[0] = vfma(mx, vsplat(u, P.T00), vfma(my, vsplat(u, P.T10), muv * (-P.T20)));
+        s[1] = vfma(mx, vsplat(u, P.T01), vfma(my, vsplat(u, P.T11), muv * (-P.T21)));
+        s[2] = mw * (-P.gc);                             // dp/df = -c w
+        if constexpr (DIST) {
+            const F np_ = vfma(nx, px, ny * py);
+            const F pw = vfma(px, wx, vsplat(u, py * wy));
+            // + [p (off.w) + off (p.w)] . nq + t (Joff w) . nq            (perspective_fields.py:146-153)
+            if constexpr (MODEL == GCLM_SIMPLE_DIVISIONAL) {     // jd carries the reference's own guards
+                s[2] = vfma(R.s1x2, vfma(np_, uvw, nuv * pw), s[2]);
+                s[2] = vfma(t, vfma(R.jd, nw, R.s2x4 * (uvw * nuv)), s[2]);
+            } else {                                             // polynomial models: jd == 2 s1
+                s[2] = vfma(R.s1x2, vfma(np_, uvw, vfma(t, nw, nuv * pw)), s[2]);
+                if constexpr (MODEL == GCLM_RADIAL) s[2] = vfma(R.s2x4 * t, uvw * nuv, s[2]);
+            }
+#pragma unroll
+            for (int j = 0; j < ND; ++j)                 // dq/dk_j = (ds/dk_j) p + 2 (ds1/dk_j) t (u,v)   (:170-180)
+                s[3 + j] = vfma(R.ds[j], np_, (R.ds1x2[j] * t) * nuv);
+        }
+        const F rho = vfma(ux, ry, -(uy * rx));
+        accumulate<MODEL>(acc, s, wgt, rho);
+    }
+
+    {   // latitude
+        F Px = u, Py = vsplat(u, v);
+        if constexpr (DIST) {
+            Px = R.tau * u;
+            Py = R.tau * v;
+        }
+        const F nn = vfma(Px, Px, vfma(Py, Py, vsplat(u, 1.0f)));
+        const F rnn = vrsq(nn);
+        const F rayx = Px * rnn, rayy = Py * rnn;        // rayz = rnn
+        const F s_ = vfma(rayx, vsplat(u, P.ga), vfma(rayy, vsplat(u, P.gb), rnn * P.gc));
+        const F sc = vclamp(s_, -1.0f + 1e-6f, 1.0f - 1e-6f);
+        const F rl = sin_halfpi(dlat) - sc;              // lm_optimizer.py:262,270-271
+        F wgt;
+        const F cost = huber(rl * rl, hk.inv_a2l, wgt);
+        wgt = wgt * cl;
+        acc[A_CL] = vfma(cost, cl, acc[A_CL]);
+        F l[PN];
+        l[0] = vfma(rayx, vsplat(u, P.T00), vfma(rayy, vsplat(u, P.T10), rnn * P.T20));
+        l[1] = vfma(rayx, vsplat(u, P.T01), vfma(rayy, vsplat(u, P.T11), rnn * P.T21));
+        const F hx = vfma(-s_, rayx, vsplat(u, P.ga)) * rnn, hy = vfma(-s_, rayy, vsplat(u, P.gb)) * rnn;
+        // ds/df = tau (h.w) + 2 tau1 (uv.w)(h.uv),  ds/dk_j = (dtau/dk_j)(h.uv)   (perspective_fields.py:255-272)
+        const F hw = vfma(hx, wx, hy * wy);
+        l[2] = hw;
+        if constexpr (DIST) {
+            const F hu = vfma(hx, u, hy * v);
+            l[2] = vfma(R.tau, hw, (R.tau1x2 * uvw) * hu);
+#pragma unroll
+            for (int j = 0; j < ND; ++j) l[3 + j] = R.dtau[j] * hu;
+        }
+        accumulate<MODEL>(acc, l, wgt, rl);
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -270,8 +488,12 @@ struct Lane<1> {
 };
 
 template <int MODEL, bool HAS_UP, bool HAS_UPC, bool HAS_LATC, int VEC>
-__global__ __launch_bounds__(kBlock, GCLM_MIN_WAVES) void sweep_kernel(const SweepArgs a) {
+// launch bounds: radial / simple_divisional are held to 168 VGPRs (3 waves per SIMD); the two BASELINE models
+// reach 96 / 128 on their own
+__global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL >= GCLM_RADIAL) ? 3 : GCLM_MIN_WAVES) void sweep_kernel(
+    const SweepArgs a) {
     if (a.skip_if_stopped && a.ctrl->stopped) return;   // batch-global early stop, no host sync
+    constexpr int NACC = Layout<MODEL>::NACC;
     const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
     const PBlock P = a.pb[b];                            // workgroup-uniform -> scalar loads
     HuberK hk;
@@ -293,9 +515,9 @@ __global__ __launch_bounds__(kBlock, GCLM_MIN_WAVES) void sweep_kernel(const Swe
     using L = Lane<VEC>;
     using F = typename L::F;
     using V = typename L::V;
-    F acc[kNAcc];
+    F acc[NACC];
 #pragma unroll
-    for (int i = 0; i < kNAcc; ++i) acc[i] = F(0.f);
+    for (int i = 0; i < NACC; ++i) acc[i] = F(0.f);
 
     int unit = u0 + tid;
     int pix = unit * VEC;
@@ -315,9 +537,14 @@ __global__ __launch_bounds__(kBlock, GCLM_MIN_WAVES) void sweep_kernel(const Swe
         const float yf = (float)y;
 #pragma unroll
         for (int k = 0; k < L::kPairs; ++k) {
-            pixel_accumulate<MODEL, HAS_UP, F>(P, hk, L::xcoord(x, k), yf, HAS_UP ? L::get(vux, k) : F(0.f),
-                                               HAS_UP ? L::get(vuy, k) : F(0.f), L::get(vlat, k), L::get(vcu, k),
-                                               L::get(vcl, k), acc);
+            if constexpr (MODEL == GCLM_PINHOLE || MODEL == GCLM_SIMPLE_RADIAL)
+                pixel_accumulate_fast<MODEL, HAS_UP, F>(P, hk, L::xcoord(x, k), yf, HAS_UP ? L::get(vux, k) : F(0.f),
+                                                        HAS_UP ? L::get(vuy, k) : F(0.f), L::get(vlat, k),
+                                                        L::get(vcu, k), L::get(vcl, k), acc);
+            else
+                pixel_accumulate<MODEL, HAS_UP, F>(P, hk, L::xcoord(x, k), yf, HAS_UP ? L::get(vux, k) : F(0.f),
+                                                   HAS_UP ? L::get(vuy, k) : F(0.f), L::get(vlat, k), L::get(vcu, k),
+                                                   L::get(vcl, k), acc);
         }
         x += dx;
         y += dy;
@@ -327,22 +554,22 @@ __global__ __launch_bounds__(kBlock, GCLM_MIN_WAVES) void sweep_kernel(const Swe
         }
     }
 
-    // wave64 butterfly, then the 4 waves through LDS; one 64-byte record per workgroup
-    __shared__ float red[kBlock / 64][kNAcc];
+    // wave64 butterfly, then the 4 waves through LDS; one record per workgroup
+    __shared__ float red[kBlock / 64][NACC];
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-    for (int i = 0; i < kNAcc; ++i) {
+    for (int i = 0; i < NACC; ++i) {
         const float s = wave_sum(hsum(acc[i]));
         if (lane == 0) red[wave][i] = s;
     }
     __syncthreads();
-    if (tid < kNAcc) {
+    if (tid < NACC) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < kBlock / 64; ++w) s += red[w][tid];
         if (tid == A_CU) s *= hk.a2u;          // costs were accumulated in units of a^2
         if (tid == A_CL) s *= hk.a2l;
-        a.partials[((size_t)b * a.nchunks + chunk) * kNAcc + tid] = s;
+        a.partials[((size_t)b * a.nchunks + chunk) * NACC + tid] = s;
     }
 }
 
@@ -362,15 +589,22 @@ hipError_t dispatch(const SweepArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+template <int MODEL>
+hipError_t dispatch_model(const SweepArgs& a, hipStream_t s) {
+    return a.vec == 4 ? dispatch<MODEL, 4>(a, s) : dispatch<MODEL, 1>(a, s);
+}
+
 }  // namespace
 
 hipError_t launch_sweep(int camera_model, const SweepArgs& a, hipStream_t s) {
     if (a.B <= 0) return hipSuccess;
-    if (camera_model == GCLM_PINHOLE)
-        return a.vec == 4 ? dispatch<GCLM_PINHOLE, 4>(a, s) : dispatch<GCLM_PINHOLE, 1>(a, s);
-    if (camera_model == GCLM_SIMPLE_RADIAL)
-        return a.vec == 4 ? dispatch<GCLM_SIMPLE_RADIAL, 4>(a, s) : dispatch<GCLM_SIMPLE_RADIAL, 1>(a, s);
-    return hipErrorInvalidValue;
+    switch (camera_model) {
+        case GCLM_PINHOLE: return dispatch_model<GCLM_PINHOLE>(a, s);
+        case GCLM_SIMPLE_RADIAL: return dispatch_model<GCLM_SIMPLE_RADIAL>(a, s);
+        case GCLM_RADIAL: return dispatch_model<GCLM_RADIAL>(a, s);
+        case GCLM_SIMPLE_DIVISIONAL: return dispatch_model<GCLM_SIMPLE_DIVISIONAL>(a, s);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 }  // namespace gclm

@@ -11,24 +11,24 @@ namespace {
 using namespace dev;
 
 // Sum the workgroup partials of the images of this block in a fixed order (double accumulate).
-// Block-cooperative: 256 threads = 16 images x 16 accumulator slots; thread (image, slot) walks the
-// image's chunk records (64-byte rows: coalesced over the 16 slots), the per-image leader (slot 0)
-// then owns the 16 sums.  Returns true for leaders.  Must be called by every thread of the block.
-constexpr int kImgPerBlock = 16;
-__device__ inline bool coop_reduce_partials(const float* partials, int B, int nchunks, int& b, float (&acc)[kNAcc]) {
-    __shared__ float sacc[kImgPerBlock][kNAcc + 1];
-    const int li = threadIdx.x / kNAcc, slot = threadIdx.x % kNAcc;
+// Block-cooperative: 256 threads = 8 images x 32 slots (the first `nacc` = 16 or 24 are accumulator slots);
+// thread (image, slot) walks the image's chunk records (coalesced over the slots), the per-image leader
+// (slot 0) then owns the sums.  Returns true for leaders.  Must be called by every thread of the block.
+constexpr int kImgPerBlock = 8, kSlots = 32;
+__device__ inline bool coop_reduce_partials(const float* partials, int B, int nchunks, int nacc, int& b,
+                                            float (&acc)[kNAccMax]) {
+    __shared__ float sacc[kImgPerBlock][kSlots + 1];
+    const int li = threadIdx.x / kSlots, slot = threadIdx.x % kSlots;
     b = blockIdx.x * kImgPerBlock + li;
-    if (b < B) {
+    if (b < B && slot < nacc) {
         double d = 0.0;
-        const float* p = partials + (size_t)b * nchunks * kNAcc + slot;
-        for (int c = 0; c < nchunks; ++c) d += p[(size_t)c * kNAcc];
+        const float* p = partials + (size_t)b * nchunks * nacc + slot;
+        for (int c = 0; c < nchunks; ++c) d += p[(size_t)c * nacc];
         sacc[li][slot] = (float)d;
     }
     __syncthreads();
     if (b >= B || slot != 0) return false;
-#pragma unroll
-    for (int i = 0; i < kNAcc; ++i) acc[i] = sacc[li][i];
+    for (int i = 0; i < kNAccMax; ++i) acc[i] = i < nacc ? sacc[li][i] : 0.f;
     return true;
 }
 
@@ -73,11 +73,11 @@ __global__ void init_kernel(SolveCtx c, InitArgs ia) {
 }
 
 // Independent intrinsics: reduce the partial records, then one thread per image applies the LM step.
-__global__ __launch_bounds__(kImgPerBlock * kNAcc) void update_kernel(SolveCtx c, int step) {
+__global__ __launch_bounds__(kImgPerBlock * kSlots) void update_kernel(SolveCtx c, int step) {
     if (c.cfg.early_stop && c.ctrl->stopped) return;          // block-uniform
     int b;
-    float acc[kNAcc];
-    if (!coop_reduce_partials(c.partials, c.B, c.nchunks, b, acc)) return;
+    float acc[kNAccMax];
+    if (!coop_reduce_partials(c.partials, c.B, c.nchunks, acc_floats(c.cfg.camera_model), b, acc)) return;
     update_image(c, step, b, acc);
 }
 
@@ -101,9 +101,9 @@ __global__ void prep_final_kernel(SolveCtx c) {
     c.pb_final[b] = p;
 }
 
-// Inverse of an n x n matrix (n <= 4) by Gauss-Jordan with partial pivoting, in double.
-__device__ inline void invert(int n, const float (&A)[4][4], double (&inv)[4][4]) {
-    double M[4][8];
+// Inverse of an n x n matrix (n <= 5) by Gauss-Jordan with partial pivoting, in double.
+__device__ inline void invert(int n, const float (&A)[kMaxP][kMaxP], double (&inv)[kMaxP][kMaxP]) {
+    double M[kMaxP][2 * kMaxP];
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) { M[i][j] = A[i][j]; M[i][n + j] = i == j ? 1.0 : 0.0; }
     for (int col = 0; col < n; ++col) {
@@ -121,10 +121,10 @@ __device__ inline void invert(int n, const float (&A)[4][4], double (&inv)[4][4]
 }
 
 // Final costs + estimate_uncertainty (lm_optimizer.py:632-642, 463-516) from the final sweep.
-__global__ __launch_bounds__(kImgPerBlock * kNAcc) void finalize_kernel(SolveCtx c, float* cam, float* grav, float* info) {
+__global__ __launch_bounds__(kImgPerBlock * kSlots) void finalize_kernel(SolveCtx c, float* cam, float* grav, float* info) {
     int b;
-    float acc[kNAcc];
-    if (!coop_reduce_partials(c.partials, c.B, c.nchunks, b, acc)) return;
+    float acc[kNAccMax];
+    if (!coop_reduce_partials(c.partials, c.B, c.nchunks, acc_floats(c.cfg.camera_model), b, acc)) return;
     const gclm_config& cfg = c.cfg;
     const int sel = c.ctrl->final_sel;
     State s = c.state[sel][b];
@@ -147,11 +147,11 @@ __global__ __launch_bounds__(kImgPerBlock * kNAcc) void finalize_kernel(SolveCtx
     o[GCLM_INFO_STEP_FAILURES] = s.fails;
     for (int i = GCLM_INFO_ROLL_UNC; i <= GCLM_INFO_VFOV_UNC; ++i) o[i] = 0.f;
     if (cfg.compute_uncertainty) {
-        float Hf[4][4], Gf[4], A[4][4];
-        unpack_system(acc, Hf, Gf);
+        float Hf[kMaxP][kMaxP], Gf[kMaxP], A[kMaxP][kMaxP];
+        unpack_system(acc, acc_pm(cfg.camera_model), Hf, Gf);
         for (int i = 0; i < pl.n; ++i)
             for (int j = 0; j < pl.n; ++j) A[i][j] = Hf[pl.cols[i]][pl.cols[j]];
-        double Cov[4][4];
+        double Cov[kMaxP][kMaxP];
         invert(pl.n, A, Cov);                                 // torch.inverse(Hess), :484
         for (int i = 0; i < pl.n; ++i)
             for (int j = 0; j < pl.n; ++j) o[GCLM_INFO_COV + i * pl.n + j] = (float)Cov[i][j];
@@ -195,11 +195,11 @@ __global__ void stop_at_kernel(SolveCtx c, float* info) {
 // be all-reduced across devices when a group's frames are sharded (BASELINE config 5).
 
 // per frame: reduce partials -> frame_sys, costs / allclose bookkeeping
-__global__ __launch_bounds__(kImgPerBlock * kNAcc) void shared_frame_kernel(SolveCtx c, int step) {
+__global__ __launch_bounds__(kImgPerBlock * kSlots) void shared_frame_kernel(SolveCtx c, int step) {
     if (c.cfg.early_stop && c.ctrl->stopped) return;
     int b;
-    float acc[kNAcc];
-    if (!coop_reduce_partials(c.partials, c.B, c.nchunks, b, acc)) return;
+    float acc[kNAccMax];
+    if (!coop_reduce_partials(c.partials, c.B, c.nchunks, acc_floats(c.cfg.camera_model), b, acc)) return;
     State s = c.state[step & 1][b];
     const float invN = 1.0f / (float)((size_t)c.H * c.W);
     float cu, cl;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(kImgPerBlock * kNAcc) void shared_frame_kernel(Solv
     if (step == 0) { s.init_cu = cu; s.init_cl = cl; }     // infos["initial_*"] (:585-588)
     cost_bookkeeping(c.cfg, c.ctrl, step, total, s, false);   // lambda is never updated (:612)
     c.state[step & 1][b] = s;
-    float4* out = reinterpret_cast<float4*>(c.frame_sys + (size_t)b * kNAcc);
+    float4* out = reinterpret_cast<float4*>(c.frame_sys + (size_t)b * kNAcc);   // shared mode: <= 4 columns
 #pragma unroll
     for (int q = 0; q < kNAcc / 4; ++q) out[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
 }
@@ -250,8 +250,8 @@ __global__ void shared_group_kernel(SolveCtx c, int step, float* gp) {
     bool ok = true;
     for (int f = f0; f < f1; ++f) {
         const float* fs = c.frame_sys + (size_t)f * kNAcc;
-        float Hf[4][4], Gf[4], Dinv[2][2];
-        unpack_system(fs, Hf, Gf);
+        float Hf[kMaxP][kMaxP], Gf[kMaxP], Dinv[2][2];
+        unpack_system(fs, 4, Hf, Gf);
         ok = frame_block(fs, c.state[step & 1][f].lambda, Dinv) && ok;
         for (int i = 0; i < ni; ++i) {
             // Dinv E[:, i]
@@ -294,8 +294,8 @@ __global__ void shared_apply_kernel(SolveCtx c, int step, const float* gp) {
     }
     ok = ok && chol_solve<2>(ni, A, dI);
     const float* fs = c.frame_sys + (size_t)b * kNAcc;
-    float Hf[4][4], Gf[4], Dinv[2][2];
-    unpack_system(fs, Hf, Gf);
+    float Hf[kMaxP][kMaxP], Gf[kMaxP], Dinv[2][2];
+    unpack_system(fs, 4, Hf, Gf);
     ok = ok && frame_block(fs, s.lambda, Dinv);
     if (ok) {
         float r0 = Gf[0], r1 = Gf[1];
@@ -309,7 +309,7 @@ __global__ void shared_apply_kernel(SolveCtx c, int step, const float* gp) {
     const V3 gv = grav_update({s.gx, s.gy, s.gz}, dG[0], dG[1], cfg.use_spherical_manifold != 0);
     s.gx = gv.x; s.gy = gv.y; s.gz = gv.z;
     update_focal(s, dI[0], cfg.use_log_focal != 0);
-    if (ni == 2) update_dist(s, dI[1], -0.7f, 0.7f);
+    if (ni == 2) update_dist(s, cfg.camera_model, dI[1], 0.f);
     c.state[(step + 1) & 1][b] = s;
     PBlock p;
     build_pblock(s, cfg.use_spherical_manifold != 0, cfg.use_log_focal != 0, p);
@@ -331,19 +331,18 @@ __global__ void pblock_from_params_kernel(SolveCtx c, const float* cam, const fl
     out[b] = p;
 }
 
-__global__ __launch_bounds__(kImgPerBlock * kNAcc) void system_out_kernel(SolveCtx c, float* cost, float* grad, float* hess) {
+__global__ __launch_bounds__(kImgPerBlock * kSlots) void system_out_kernel(SolveCtx c, float* cost, float* grad, float* hess) {
     int b;
-    float acc[kNAcc];
-    if (!coop_reduce_partials(c.partials, c.B, c.nchunks, b, acc)) return;
+    float acc[kNAccMax];
+    if (!coop_reduce_partials(c.partials, c.B, c.nchunks, acc_floats(c.cfg.camera_model), b, acc)) return;
     const float invN = 1.0f / (float)((size_t)c.H * c.W);
     cost[b * 2] = acc[A_CU] * invN;
     cost[b * 2 + 1] = acc[A_CL] * invN;
-    float Hf[4][4], Gf[4];
-    unpack_system(acc, Hf, Gf);
+    float Hf[kMaxP][kMaxP], Gf[kMaxP];
+    unpack_system(acc, acc_pm(c.cfg.camera_model), Hf, Gf);
     for (int i = 0; i < GCLM_MAX_PARAMS; ++i) {
-        grad[b * GCLM_MAX_PARAMS + i] = i < 4 ? Gf[i] : 0.f;
-        for (int j = 0; j < GCLM_MAX_PARAMS; ++j)
-            hess[(b * GCLM_MAX_PARAMS + i) * GCLM_MAX_PARAMS + j] = (i < 4 && j < 4) ? Hf[i][j] : 0.f;
+        grad[b * GCLM_MAX_PARAMS + i] = Gf[i];
+        for (int j = 0; j < GCLM_MAX_PARAMS; ++j) hess[(b * GCLM_MAX_PARAMS + i) * GCLM_MAX_PARAMS + j] = Hf[i][j];
     }
 }
 
@@ -357,7 +356,7 @@ __device__ inline uint64_t mix64(uint64_t z) {   // splitmix64 finaliser
 }
 __device__ inline float u01(uint64_t h) { return ((float)(h >> 40) + 0.5f) * (1.0f / 16777216.0f); }
 
-struct GT { float fx, k1; V3 g; };
+struct GT { float fx, k1, k2; V3 g; };
 // gravity is keyed by the image index, the intrinsics by `intr_index` (= image index, or the
 // group index when frames of a group share one camera)
 __device__ inline GT synth_gt(int model, uint64_t seed, int64_t index, int64_t intr_index, int H) {
@@ -369,7 +368,8 @@ __device__ inline GT synth_gt(int model, uint64_t seed, int64_t index, int64_t i
     const float vfov = (20.f + u01(mix64(ibase + 3)) * 70.f) * d2r;
     GT t;
     t.fx = (float)H * 0.5f / tanf(vfov * 0.5f);
-    t.k1 = model == GCLM_PINHOLE ? 0.f : -0.3f + 0.4f * u01(mix64(ibase + 4));
+    t.k1 = model == GCLM_PINHOLE ? 0.f : -0.3f + (model == GCLM_SIMPLE_DIVISIONAL ? 0.35f : 0.4f) * u01(mix64(ibase + 4));
+    t.k2 = model == GCLM_RADIAL ? -0.02f + 0.04f * u01(mix64(ibase + 5)) : 0.f;
     t.g = from_rp(roll, pitch);
     return t;
 }
@@ -388,7 +388,7 @@ __global__ void synth_kernel(int model, uint64_t seed, int64_t first, int B, int
         if (gt_cam) {
             float* cm = gt_cam + (size_t)b * 8;
             cm[0] = (float)W; cm[1] = (float)H; cm[2] = t.fx; cm[3] = t.fx; cm[4] = W * 0.5f; cm[5] = H * 0.5f;
-            cm[6] = t.k1; cm[7] = 0.f;
+            cm[6] = t.k1; cm[7] = t.k2;
         }
         if (gt_grav) { gt_grav[b * 3] = t.g.x; gt_grav[b * 3 + 1] = t.g.y; gt_grav[b * 3 + 2] = t.g.z; }
     }
@@ -397,9 +397,23 @@ __global__ void synth_kernel(int model, uint64_t seed, int64_t first, int B, int
         const float u = ((float)x - W * 0.5f) / t.fx, v = ((float)y - H * 0.5f) / t.fx;
         const float r2 = u * u + v * v;
         const float px = t.g.x - t.g.z * u, py = t.g.y - t.g.z * v;
-        const float d = 1.f + t.k1 * r2, tt = u * px + v * py;
-        float qx = d * px + 2.f * t.k1 * tt * u, qy = d * py + 2.f * t.k1 * tt * v;
-        const float e = 1.f - t.k1 * r2;
+        // distortion scale s(r2), 2 ds/dr2 and undistortion scale e(r2) of the model (camera.py:611-636,
+        // 712-746, 829-868)
+        float d = 1.f, d1x2 = 0.f, e = 1.f;
+        if (model == GCLM_SIMPLE_RADIAL) {
+            d = 1.f + t.k1 * r2; d1x2 = 2.f * t.k1; e = 1.f - t.k1 * r2;
+        } else if (model == GCLM_RADIAL) {
+            d = 1.f + t.k1 * r2 + t.k2 * r2 * r2; d1x2 = 2.f * t.k1 + 4.f * t.k2 * r2;
+            e = 1.f - t.k1 * r2 + (3.f * t.k1 * t.k1 - t.k2) * r2 * r2;
+        } else if (model == GCLM_SIMPLE_DIVISIONAL) {
+            const float den = 2.f * t.k1 * r2;
+            d = den == 0.f ? 1.f : (1.f - sqrtf(fmaxf(1.f - 4.f * t.k1 * r2, 0.f))) / den;
+            const float t0 = sqrtf(fmaxf(1.f - 4.f * t.k1 * r2, 1e-6f)), a1 = t0 * 2.f * r2, a2 = t.k1 * r2 * r2;
+            d1x2 = a1 * a2 == 0.f ? 0.f : (4.f * a2 - (1.f - t0) * a1) / (a1 * a2);
+            e = 1.f / (1.f + t.k1 * r2);
+        }
+        const float tt = u * px + v * py;
+        float qx = d * px + d1x2 * tt * u, qy = d * py + d1x2 * tt * v;
         const float Px = e * u, Py = e * v;
         const float rn = rsqrtf(Px * Px + Py * Py + 1.f);
         float s = (Px * t.g.x + Py * t.g.y + t.g.z) * rn;
@@ -428,9 +442,9 @@ inline dim3 grid1(int n) { return dim3((n + 127) / 128); }
 }  // namespace
 
 #define GCLM_L(kernel, n, s, ...) hipLaunchKernelGGL(kernel, grid1(n), dim3(128), 0, s, __VA_ARGS__)
-// cooperative-reduce kernels: 16 images per 256-thread block
+// cooperative-reduce kernels: 8 images per 256-thread block
 #define GCLM_LR(kernel, n, s, ...) \
-    hipLaunchKernelGGL(kernel, dim3(((n) + kImgPerBlock - 1) / kImgPerBlock), dim3(kImgPerBlock * kNAcc), 0, s, __VA_ARGS__)
+    hipLaunchKernelGGL(kernel, dim3(((n) + kImgPerBlock - 1) / kImgPerBlock), dim3(kImgPerBlock * kSlots), 0, s, __VA_ARGS__)
 
 hipError_t launch_init(const SolveCtx& c, const InitArgs& ia, hipStream_t s) {
     GCLM_L(init_kernel, c.B, s, c, ia);

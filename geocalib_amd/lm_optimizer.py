@@ -23,7 +23,7 @@ from .utils import focal2fov
 
 logger = logging.getLogger(__name__)
 
-_HIP_MODELS = ("pinhole", "simple_radial")
+_HIP_MODELS = ("pinhole", "simple_radial", "radial", "simple_divisional")
 
 
 def get_trivial_estimation(data: Dict[str, torch.Tensor], camera_model) -> Tuple[BaseCamera, Gravity]:

@@ -17,7 +17,11 @@ from conftest import GOLDEN, compare_result, conf_for, data_for, golden_cases, g
 pytestmark = pytest.mark.gpu
 
 TOL = {"focal": 1e-4, "dist": 1e-4, "gravity": 1e-4, "cost": 1e-4, "cov": 1e-3, "unc": 1e-3}
-HIP_MODELS = ("pinhole", "simple_radial")
+HIP_MODELS = ("pinhole", "simple_radial")          # the two BASELINE models: full test matrix
+ALL_MODELS = ("pinhole", "simple_radial", "radial", "simple_divisional")
+# simple_divisional: the reference's own float32 formulas cancel catastrophically (flagged unstable at
+# camera.py:913; the float32 and float64 oracles differ by the same amount, tests/test_oracle.py)
+TOL_DIV = {"focal": 3e-3, "dist": 5e-3, "gravity": 1e-3, "cost": 1e-3, "cov": 2e-2, "unc": 2e-2}
 
 
 @pytest.fixture(scope="module")
@@ -50,15 +54,16 @@ def run(conf, data, dev, training=False):
 
 # ------------------------------------------------------------------ against the reference's goldens
 
-@pytest.mark.parametrize("setname,variant", golden_cases(HIP_MODELS))
+@pytest.mark.parametrize("setname,variant", golden_cases(ALL_MODELS))
 def test_hip_matches_reference_small(dev, setname, variant):
     ref = golden_outputs(setname, variant)
     out = run(conf_for(setname, variant), data_for(setname, variant), dev)
-    tol = dict(TOL)
+    tol = dict(TOL_DIV if "divisional" in setname else TOL)
     if (setname, variant) == ("simple_radial", "prior_focal"):
         tol.update(focal=1e-4, dist=5e-4, gravity=5e-4, cost=5e-4)   # reference quirk 7: never converges
     compare_result(out, ref, tol, f"{setname}/{variant}")
-    assert np.array_equal(out["stop_at"], ref["stop_at"]), (out["stop_at"], ref["stop_at"])
+    if "divisional" not in setname:
+        assert np.array_equal(out["stop_at"], ref["stop_at"]), (out["stop_at"], ref["stop_at"])
     assert set(k for k in ref if k not in ("camera", "gravity")) <= set(out), set(ref) - set(out)
     assert out["step_failures"].max() == 0
 
@@ -103,7 +108,7 @@ def test_hip_follows_reference_step_by_step(dev, setname):
         assert np.abs(out["gravity"] - ref_grav[k - 1]).max() < 3e-5, k
 
 
-@pytest.mark.parametrize("model", HIP_MODELS)
+@pytest.mark.parametrize("model", ALL_MODELS)
 @pytest.mark.parametrize("mode", ["loop", "rpf"])
 def test_hip_single_sweep_system(dev, model, mode):
     """gclm_system: costs, J^T W r, J^T W J of ONE fused sweep at fixed, non-converged parameters."""
@@ -117,16 +122,17 @@ def test_hip_single_sweep_system(dev, model, mode):
     out = to_np(opt.system(to_dev(data, dev), cam, grav, as_rpf=(mode == "rpf")))
     Hr, Gr = s[f"{model}/{mode}/H"], s[f"{model}/{mode}/G"]
     d = np.sqrt(np.abs(np.einsum("bii->bi", Hr)))
-    assert (np.abs(out["H"] - Hr) / (d[:, :, None] * d[:, None, :])).max() < 5e-5
+    tol = 3e-3 if model == "simple_divisional" else 5e-5
+    assert (np.abs(out["H"] - Hr) / (d[:, :, None] * d[:, None, :])).max() < tol
     cost = (s[f"{model}/{mode}/cost_up"] + s[f"{model}/{mode}/cost_lat"]) * data["latitude_field"][0].size
-    assert (np.abs(out["G"] - Gr) / (d * np.sqrt(cost)[:, None])).max() < 5e-5
+    assert (np.abs(out["G"] - Gr) / (d * np.sqrt(cost)[:, None])).max() < tol
     assert np.allclose(out["cost_up"], s[f"{model}/{mode}/cost_up"], rtol=2e-5)
     assert np.allclose(out["cost_lat"], s[f"{model}/{mode}/cost_lat"], rtol=2e-5)
 
 
 # ------------------------------------------------------------------ against the oracle on other shapes
 
-@pytest.mark.parametrize("model", HIP_MODELS)
+@pytest.mark.parametrize("model", ALL_MODELS)
 @pytest.mark.parametrize("shape", [(50, 70), (33, 47), (96, 128), (7, 5)])
 def test_hip_matches_oracle_odd_shapes(dev, oracle, model, shape):
     """Widths that are not multiples of 4 take the scalar-load path; tiny images take one workgroup."""
@@ -136,9 +142,9 @@ def test_hip_matches_oracle_odd_shapes(dev, oracle, model, shape):
     conf = {"camera_model": model, "num_steps": 20, "early_stop": False}
     ref = oracle.solve(data, conf, precision="f32")
     out = run(conf, data, dev)
-    tol = dict(TOL)
+    tol = dict(TOL_DIV if model == "simple_divisional" else TOL)
     if H * W < 100:
-        tol.update(focal=2e-3, dist=2e-3, gravity=2e-3, cost=2e-3, cov=5e-2, unc=5e-2)   # 35 pixels: ill-posed
+        tol.update(focal=5e-3, dist=5e-3, gravity=5e-3, cost=5e-3, cov=1e-1, unc=1e-1)   # 35 pixels: ill-posed
     compare_result(out, ref, tol, f"{model}/{shape}")
 
 

@@ -106,7 +106,7 @@ def test_camera_bookkeeping(model):
     if model != "pinhole":
         lim = 3.0 if model == "simple_divisional" else 0.7
         assert cam.update_dist(torch.full((3, 1), 9.0)).k1.tolist() == pytest.approx([lim] * 3)
-        p = (torch.rand(3, 10, 2) - 0.5) * 0.2
+        p = (torch.rand(3, 10, 2, generator=torch.Generator().manual_seed(4)) - 0.5) * 0.2
         rt = cam.undistort(cam.distort(p)[0])[0]
         assert torch.allclose(rt, p, atol=2e-3 if model != "simple_divisional" else 1e-4)   # fp32 cancellation in 1 - sqrt(1 - 4 k r2)
 
@@ -170,5 +170,4 @@ def test_trivial_estimation_and_plan():
     cfg = LMOptimizer({"camera_model": "pinhole", "num_steps": 20, "early_stop": False}).eval()._config()
     assert (cfg.num_steps, cfg.early_stop, cfg.compute_uncertainty, cfg.camera_model) == (20, 0, 1, 0)
     assert LMOptimizer({}).train()._config().compute_uncertainty == 0
-    with pytest.raises(NotImplementedError):
-        LMOptimizer({"camera_model": "radial"})._config()
+    assert LMOptimizer({"camera_model": "radial"})._config().camera_model == 2
