@@ -71,6 +71,9 @@ __device__ __forceinline__ float vclamp(float a, float lo, float hi) { return fm
 __device__ __forceinline__ f2 vclamp(f2 a, float lo, float hi) {
     return f2{fminf(fmaxf(a.x, lo), hi), fminf(fmaxf(a.y, lo), hi)};
 }
+// min(a, 1)
+__device__ __forceinline__ float vmin1(float a) { return fminf(a, 1.0f); }
+__device__ __forceinline__ f2 vmin1(f2 a) { return f2{fminf(a.x, 1.0f), fminf(a.y, 1.0f)}; }
 // select(y <= 1, a, b)
 __device__ __forceinline__ float vsel_le1(float y, float a, float b) { return y <= 1.0f ? a : b; }
 __device__ __forceinline__ f2 vsel_le1(f2 y, f2 a, f2 b) {
@@ -100,16 +103,23 @@ __device__ __forceinline__ F sin_halfpi(F x) {
 }
 
 // Scaled Huber on the squared residual x2 (lm_optimizer.py:61-87), in units of a^2: returns
-// cost / a^2 (the a^2 factor is applied once per workgroup) and sets the weight.
+// cost / a^2 (the a^2 factor is applied once per workgroup) and sets the weight.  Branch-free form:
+//   weight = min(1, 1/sqrt(y + 1e-8))           (= 1 for y <= 1, = 1/sqrt(y) beyond)
+//   cost   = 2 y weight - min(y, 1)             (= y for y <= 1, = 2 sqrt(y) - 1 beyond)
+// identical to the reference's where(y <= 1, ...) selects up to 2e-8 relative (the 1e-8 inside the sqrt).
 // The reference's max(eps, 1/sqrt(y)) only matters for y > 7e13; residuals here are bounded
 // (|r_up| <= 2, |r_lat| <= 2 => y <= 4/a^2), so it is the identity and is dropped.
 template <typename F>
 __device__ __forceinline__ F huber(F x2, float inv_a2, F& weight) {
     const F y = x2 * inv_a2;
-    const F yy = y + 1e-8f;
-    const F isx = vrsq(yy);
+    const F isx = vrsq(y + 1e-8f);
+#if GCLM_HUBER_SELECT      // A/B switch: the reference's literal select form
     weight = vsel_le1(y, vsplat(y, 1.0f), isx);
-    return vsel_le1(y, y, vfma(2.0f * yy, isx, vsplat(y, -1.0f)));
+    return vsel_le1(y, y, vfma(2.0f * (y + 1e-8f), isx, vsplat(y, -1.0f)));
+#else
+    weight = vmin1(isx);
+    return vfma(2.0f * y, weight, -vmin1(y));
+#endif
 }
 
 struct HuberK {
