@@ -545,6 +545,14 @@ __global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL >= GCLM_RADIAL) ? 3 : GC
         if constexpr (HAS_UP && HAS_UPC) vcu = L::ld(upc, unit);
         if constexpr (HAS_LATC) vcl = L::ld(latc, unit);
         const float yf = (float)y;
+#if GCLM_NOMATH     // measurement only: the memory-system ceiling of this exact access pattern
+#pragma unroll
+        for (int k = 0; k < L::kPairs; ++k)
+            acc[0] = acc[0] + (HAS_UP ? L::get(vux, k) + L::get(vuy, k) : F(0.f)) + L::get(vlat, k) + L::get(vcu, k) + L::get(vcl, k);
+        (void)yf;
+        (void)hk;
+        (void)P;
+#else
 #pragma unroll
         for (int k = 0; k < L::kPairs; ++k) {
             if constexpr (MODEL == GCLM_PINHOLE || MODEL == GCLM_SIMPLE_RADIAL)
@@ -556,6 +564,7 @@ __global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL >= GCLM_RADIAL) ? 3 : GC
                                                    HAS_UP ? L::get(vuy, k) : F(0.f), L::get(vlat, k), L::get(vcu, k),
                                                    L::get(vcl, k), acc);
         }
+#endif
         x += dx;
         y += dy;
         if (x >= a.W) {

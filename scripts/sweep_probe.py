@@ -19,6 +19,6 @@ for model in models:
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / n
     k, ms = C.c_int(0), C.c_float(0); lib.gclm_last_pass_timing(h.ptr, C.byref(k), C.byref(ms))
     avg = ms.value / k.value
-    ferr = (out["camera"]._data[:, 3] / gtc[:, 3] - 1).abs().median().item()
+    ferr = (out["camera"]._data[:, 3] / gtc[:, 3] - 1).abs().nanmedian().item()
     print(f"{model:14s} B={B:5d}: sweep {avg*1e3:8.1f} us = {B*H*W*20/avg/1e9:6.2f} TB/s | solve {dt*1e3:7.2f} ms = {B/dt:8.0f} img/s | f err {ferr:.1e}", flush=True)
     del d
