@@ -324,6 +324,9 @@ int gclm_calibrate(gclm_handle* h, const float* d_up, const float* d_lat, const 
     ia.prior_gravity = d_prior_gravity;
     ia.prior_dist = d_prior_dist;
     ia.prior_dist_cols = prior_dist_cols;
+    ia.up = d_up;
+    ia.lat = d_lat;
+    if (h->cfg.heuristic_init && !d_up) return fail(h, -3, "gclm_calibrate: heuristic_init needs the up field");
     return run_solve(h, d_up, d_lat, d_up_conf, d_lat_conf, B, H, W, ia, d_cam_out, d_grav_out, d_info_out, stream);
 }
 

@@ -103,6 +103,8 @@ struct InitArgs {              // initial estimate: explicit (cam, grav) or triv
     const float* prior_gravity; // (B,3) or nullptr
     const float* prior_dist;    // (B, prior_dist_cols) or nullptr
     int prior_dist_cols;
+    const float* up;            // heuristic initialisation reads three pixels of the fields
+    const float* lat;
 };
 hipError_t launch_init(const SolveCtx& c, const InitArgs& ia, hipStream_t s);
 hipError_t launch_update(const SolveCtx& c, int step, hipStream_t s);

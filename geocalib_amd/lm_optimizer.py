@@ -104,7 +104,14 @@ class LMOptimizer(nn.Module):
         # extension: frames per shared-intrinsics group (None = the whole batch is one group,
         # which is the reference's only mode; lm_optimizer.py:350-383)
         "group_size": None,
+        # knobs of the training-time optimiser (siclib/models/optimization/lm_optimizer.py:37-59)
+        "loss_fn": "huber_loss",          # {"huber_loss", "squared_loss"}
+        "init_conf": {"name": "trivial"},  # {"trivial", "heuristic"} (siclib/models/optimization/utils.py:16-82)
     }
+
+    # squared_loss (siclib/models/optimization/losses.py:26) is the Huber loss with an unreachable threshold:
+    # with a = 2^20 every residual is an inlier, weight = 1 and cost = (x / a^2) a^2 = x exactly (power of two).
+    _SQUARED_LOSS_SCALE = float(2 ** 20)
 
     def __init__(self, conf: Dict[str, Any] = None):
         super().__init__()
@@ -159,8 +166,13 @@ class LMOptimizer(nn.Module):
         cfg.atol, cfg.rtol = float(c.atol), float(c.rtol)
         cfg.use_spherical_manifold = int(bool(c.use_spherical_manifold))
         cfg.use_log_focal = int(bool(c.use_log_focal))
-        cfg.up_loss_fn_scale = float(c.up_loss_fn_scale)
-        cfg.lat_loss_fn_scale = float(c.lat_loss_fn_scale)
+        assert c.loss_fn in ("huber_loss", "squared_loss"), f"Unknown loss_fn: {c.loss_fn}"
+        squared = c.loss_fn == "squared_loss"
+        cfg.up_loss_fn_scale = self._SQUARED_LOSS_SCALE if squared else float(c.up_loss_fn_scale)
+        cfg.lat_loss_fn_scale = self._SQUARED_LOSS_SCALE if squared else float(c.lat_loss_fn_scale)
+        init_name = c.init_conf["name"] if isinstance(c.init_conf, dict) else getattr(c.init_conf, "name", "trivial")
+        assert init_name in ("trivial", "heuristic"), f"Unknown initialisation: {init_name}"
+        cfg.heuristic_init = int(init_name == "heuristic")
         cfg.estimate_gravity = int(self.estimate_gravity)
         cfg.estimate_focal = int(self.estimate_focal)
         cfg.estimate_dist = int(self.estimate_dist)

@@ -80,6 +80,8 @@ typedef struct gclm_config {
     int32_t estimate_focal;          /* :209-212 */
     int32_t estimate_dist;           /* :214-221 */
     int32_t compute_uncertainty;     /* eval mode: estimate_uncertainty (:635-636) */
+    int32_t heuristic_init;          /* gclm_calibrate only: siclib's get_heuristic_estimation instead of the trivial
+                                        estimate (siclib/models/optimization/utils.py:27-82; needs the up field) */
 } gclm_config;
 
 typedef struct gclm_handle gclm_handle;

@@ -86,6 +86,7 @@ typedef struct {
     double up_loss_fn_scale, lat_loss_fn_scale;
     int training;            /* nn.Module.training: skips estimate_uncertainty (:635) */
     int num_threads;         /* OpenMP threads over images / pixel rows; <=0: library default */
+    int heuristic_init;      /* siclib/models/optimization/utils.py:27-82 instead of the trivial estimate */
 } oracle_conf;
 
 typedef struct {
@@ -679,6 +680,30 @@ static void oracle_init(const oracle_conf *cf, const oracle_data *d, int b, cam_
         if (nd > 1) c->k2 = (real)d->prior_dist[b * nd + 1];
     }
     *g = from_rp(0, 0);
+    if (cf->heuristic_init && d->up && d->lat) {
+        /* siclib get_heuristic_estimation: roll from the up vector at the centre, pitch = latitude at the
+         * centre, vfov = |lat(top) - lat(bottom)| on the central column; clamps as there */
+        const int N = d->H * d->W, yc = d->H / 2, xc = d->W / 2;
+        const float *up = d->up + (size_t)b * 2 * N, *lat = d->lat + (size_t)b * N;
+        const real d45 = R(45.0) / R(180.0) * (real)M_PI;
+#ifdef ORACLE_F64
+        real roll = -atan2((real)up[yc * d->W + xc], -(real)up[N + yc * d->W + xc]);
+#else
+        real roll = -atan2f(up[yc * d->W + xc], -up[N + yc * d->W + xc]);
+#endif
+        roll = roll < -d45 ? -d45 : (roll > d45 ? d45 : roll);
+        real pitch = (real)lat[yc * d->W + xc];
+        pitch = pitch < -d45 ? -d45 : (pitch > d45 ? d45 : pitch);
+        real vf = rfabs((real)lat[xc] - (real)lat[(d->H - 1) * d->W + xc]);
+        const real lo = R(20.0) / R(180.0) * (real)M_PI, hi = R(120.0) / R(180.0) * (real)M_PI;
+        vf = vf < lo ? lo : (vf > hi ? hi : vf);
+        if (!d->prior_focal) {
+            real fh = h / R(2.0) / rtan(vf / R(2.0));
+            c->fy = fh;
+            c->fx = d->scales ? fh * (real)d->scales[0] / (real)d->scales[1] : fh;
+        }
+        *g = from_rp(roll, pitch);
+    }
     if (d->prior_gravity) {
         vec3 pg = {(real)d->prior_gravity[b * 3], (real)d->prior_gravity[b * 3 + 1], (real)d->prior_gravity[b * 3 + 2]};
         *g = normalize3(pg);

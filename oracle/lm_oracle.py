@@ -19,6 +19,8 @@ DEFAULT_CONF = {  # lm_optimizer.py:144-162
     "fix_lambda": False, "early_stop": True, "atol": 1e-8, "rtol": 1e-8,
     "use_spherical_manifold": True, "use_log_focal": True,
     "up_loss_fn_scale": 1e-2, "lat_loss_fn_scale": 1e-2, "verbose": False,
+    # siclib knobs (siclib/models/optimization/lm_optimizer.py:37-59)
+    "loss_fn": "huber_loss", "init_conf": {"name": "trivial"}, "group_size": None,
 }
 
 
@@ -27,7 +29,8 @@ class _Conf(C.Structure):
                 ("lambda0", C.c_double), ("fix_lambda", C.c_int), ("early_stop", C.c_int),
                 ("atol", C.c_double), ("rtol", C.c_double), ("use_spherical_manifold", C.c_int),
                 ("use_log_focal", C.c_int), ("up_loss_fn_scale", C.c_double),
-                ("lat_loss_fn_scale", C.c_double), ("training", C.c_int), ("num_threads", C.c_int)]
+                ("lat_loss_fn_scale", C.c_double), ("training", C.c_int), ("num_threads", C.c_int),
+                ("heuristic_init", C.c_int)]
 
 
 _FP = C.POINTER(C.c_float)
@@ -76,8 +79,9 @@ def _pack(conf, data, training=False, num_threads=0):
     c = _Conf(CAMERA_MODELS[cf["camera_model"]], int(cf["shared_intrinsics"]), int(cf["num_steps"]),
               float(cf["lambda_"]), int(cf["fix_lambda"]), int(cf["early_stop"]), float(cf["atol"]),
               float(cf["rtol"]), int(cf["use_spherical_manifold"]), int(cf["use_log_focal"]),
-              float(cf["up_loss_fn_scale"]), float(cf["lat_loss_fn_scale"]), int(training),
-              int(num_threads))
+              float(2 ** 20 if cf["loss_fn"] == "squared_loss" else cf["up_loss_fn_scale"]),
+              float(2 ** 20 if cf["loss_fn"] == "squared_loss" else cf["lat_loss_fn_scale"]), int(training),
+              int(num_threads), int(cf["init_conf"]["name"] == "heuristic"))
     keep = {k: _f32(data.get(k)) for k in ("up_field", "latitude_field", "up_confidence",
                                            "latitude_confidence", "scales", "prior_focal",
                                            "prior_gravity", "prior_dist")}

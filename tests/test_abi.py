@@ -56,7 +56,7 @@ def test_default_config_matches_reference_defaults():
     assert cfg.use_spherical_manifold == 1 and cfg.use_log_focal == 1
     assert cfg.up_loss_fn_scale == pytest.approx(1e-2) and cfg.lat_loss_fn_scale == pytest.approx(1e-2)
     assert cfg.estimate_gravity == cfg.estimate_focal == cfg.estimate_dist == cfg.compute_uncertainty == 1
-    assert C.sizeof(_lib.GclmConfig) == 17 * 4
+    assert cfg.heuristic_init == 0 and C.sizeof(_lib.GclmConfig) == 18 * 4
 
 
 def test_create_rejects_bad_config_with_message():

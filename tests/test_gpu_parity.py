@@ -364,3 +364,20 @@ def test_split_protocol_two_virtual_ranks(dev, model):
     # one focal per group
     f = single["camera"][:, 3].reshape(G, gs)
     assert np.abs(f / f[:, :1] - 1).max() < 1e-6
+
+
+@pytest.mark.parametrize("model", HIP_MODELS)
+@pytest.mark.parametrize("knob", ["heuristic", "squared_loss"])
+def test_hip_matches_reference_siclib_knobs(dev, model, knob):
+    """siclib's training-time knobs: heuristic initialisation evaluated in the device init kernel, and the
+    squared loss (= Huber with an unreachable threshold, exact by power-of-two scaling)."""
+    g = np.load(os.path.join(GOLDEN, "golden_extra.npz"))
+    ref = {k.split("/", 2)[2]: g[k] for k in g.files if k.startswith(f"{model}/{knob}/")}
+    conf = {"camera_model": model, "num_steps": 20, "early_stop": False}
+    conf |= {"init_conf": {"name": "heuristic"}} if knob == "heuristic" else {"loss_fn": "squared_loss"}
+    out = run(conf, data_for(model, "bench"), dev)
+    compare_result(out, ref, TOL, f"{model}/{knob}")
+    if knob == "heuristic":
+        init = run({**conf, "num_steps": 0}, data_for(model, "bench"), dev)
+        assert np.allclose(init["camera"], ref["init_camera"], rtol=5e-6)
+        assert np.allclose(init["gravity"], ref["init_gravity"], atol=5e-6)

@@ -132,3 +132,20 @@ def test_oracle_render_matches_reference_fields(oracle):
     data, cams, gravs = synth.make_fields(5, range(2), "simple_radial", 48, 64, noise=0.0, confidences=False)
     s = oracle.system(data, cams, gravs, {"camera_model": "simple_radial"}, precision="f64")
     assert s["cost_up"].max() < 1e-12 and s["cost_lat"].max() < 1e-12
+
+
+@pytest.mark.parametrize("model", ["pinhole", "simple_radial"])
+@pytest.mark.parametrize("knob", ["heuristic", "squared_loss"])
+def test_oracle_matches_reference_siclib_knobs(oracle, model, knob):
+    """Training-time knobs (siclib): heuristic initialisation (utils.py:27-82) and squared loss (losses.py:26);
+    goldens from tests/golden/make_golden_extra.py."""
+    g = np.load(os.path.join(GOLDEN, "golden_extra.npz"))
+    ref = {k.split("/", 2)[2]: g[k] for k in g.files if k.startswith(f"{model}/{knob}/")}
+    conf = {"camera_model": model, "num_steps": 20, "early_stop": False}
+    conf |= {"init_conf": {"name": "heuristic"}} if knob == "heuristic" else {"loss_fn": "squared_loss"}
+    out = oracle.solve(data_for(model, "bench"), conf, precision="f32")
+    compare_result(out, ref, TIGHT, f"{model}/{knob}")
+    if knob == "heuristic":     # and the initial estimate itself (0 LM steps)
+        init = oracle.solve(data_for(model, "bench"), {**conf, "num_steps": 0}, precision="f32")
+        assert np.allclose(init["camera"], ref["init_camera"], rtol=2e-6)
+        assert np.allclose(init["gravity"], ref["init_gravity"], atol=2e-6)
