@@ -424,6 +424,19 @@ int gclm_shared_finish(gclm_handle* h, float* d_info_out, void* stream) {
     return 0;
 }
 
+int gclm_pack_fields(const float* d_up_raw, const float* d_up_logconf, const float* d_lat_raw,
+                     const float* d_lat_logconf, int B, int H, int W, float* d_up, float* d_up_conf, float* d_lat,
+                     float* d_lat_conf, void* stream) {
+    if (!d_up_raw || !d_lat_raw || !d_up || !d_lat || B < 0 || H <= 0 || W <= 0) return -3;
+    if ((d_up_logconf && !d_up_conf) || (d_lat_logconf && !d_lat_conf)) return -3;
+    const bool vec4 = ((size_t)H * W) % 4 == 0 && is_aligned16(d_up_raw) && is_aligned16(d_up_logconf) &&
+                      is_aligned16(d_lat_raw) && is_aligned16(d_lat_logconf) && is_aligned16(d_up) &&
+                      is_aligned16(d_up_conf) && is_aligned16(d_lat) && is_aligned16(d_lat_conf);
+    hipError_t e = launch_pack_fields(d_up_raw, d_up_logconf, d_lat_raw, d_lat_logconf, B, H, W, vec4, d_up, d_up_conf,
+                                      d_lat, d_lat_conf, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : -10;
+}
+
 int gclm_synth_fields_grouped(int camera_model, uint64_t seed, int64_t first_index, int B, int H, int W,
                               float noise_sigma, int group_size, int run, int run_stride, float* d_up,
                               float* d_lat, float* d_up_conf, float* d_lat_conf, float* d_gt_cam,

@@ -458,6 +458,59 @@ __global__ void synth_kernel(int model, uint64_t seed, int64_t first, int B, int
     }
 }
 
+// ---------------------------------------------------------------- CNN-head epilogue (the step before the path)
+// UpDecoder / LatitudeDecoder epilogues (geocalib.py:57,73-75) fused into ONE pass that writes the five
+// planes the sweep reads: up = normalize(raw, dim=1), latitude = asin(clamp(tanh(raw), +-(1-1e-5))),
+// confidences = sigmoid(log-confidence).  Eager PyTorch runs 8 elementwise kernels and ~18 plane passes.
+template <int VEC>
+__global__ void pack_fields_kernel(const float* __restrict__ up_raw, const float* __restrict__ up_lc,
+                                   const float* __restrict__ lat_raw, const float* __restrict__ lat_lc, int B,
+                                   size_t N, float* __restrict__ up, float* __restrict__ upc,
+                                   float* __restrict__ lat, float* __restrict__ latc) {
+    const size_t units = N / VEC;
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {
+        const float* ux = up_raw + (size_t)b * 2 * N;
+        const float* uy = ux + N;
+        float* ox = up + (size_t)b * 2 * N;
+        float* oy = ox + N;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < units; i += (size_t)gridDim.x * blockDim.x) {
+            float vx[VEC], vy[VEC], vl[VEC], c1[VEC], c2[VEC];
+            if constexpr (VEC == 4) {
+                const float4 a = reinterpret_cast<const float4*>(ux)[i], bq = reinterpret_cast<const float4*>(uy)[i];
+                const float4 l = reinterpret_cast<const float4*>(lat_raw + (size_t)b * N)[i];
+                vx[0] = a.x; vx[1] = a.y; vx[2] = a.z; vx[3] = a.w;
+                vy[0] = bq.x; vy[1] = bq.y; vy[2] = bq.z; vy[3] = bq.w;
+                vl[0] = l.x; vl[1] = l.y; vl[2] = l.z; vl[3] = l.w;
+                if (up_lc) { const float4 t = reinterpret_cast<const float4*>(up_lc + (size_t)b * N)[i]; c1[0] = t.x; c1[1] = t.y; c1[2] = t.z; c1[3] = t.w; }
+                if (lat_lc) { const float4 t = reinterpret_cast<const float4*>(lat_lc + (size_t)b * N)[i]; c2[0] = t.x; c2[1] = t.y; c2[2] = t.z; c2[3] = t.w; }
+            } else {
+                vx[0] = ux[i]; vy[0] = uy[i]; vl[0] = lat_raw[(size_t)b * N + i];
+                if (up_lc) c1[0] = up_lc[(size_t)b * N + i];
+                if (lat_lc) c2[0] = lat_lc[(size_t)b * N + i];
+            }
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float n = fmaxf(sqrtf(vx[k] * vx[k] + vy[k] * vy[k]), 1e-12f);     // F.normalize eps
+                vx[k] /= n; vy[k] /= n;
+                vl[k] = asinf(fminf(fmaxf(tanhf(vl[k]), -1.0f + 1e-5f), 1.0f - 1e-5f));
+                if (up_lc) c1[k] = 1.0f / (1.0f + expf(-c1[k]));
+                if (lat_lc) c2[k] = 1.0f / (1.0f + expf(-c2[k]));
+            }
+            if constexpr (VEC == 4) {
+                reinterpret_cast<float4*>(ox)[i] = make_float4(vx[0], vx[1], vx[2], vx[3]);
+                reinterpret_cast<float4*>(oy)[i] = make_float4(vy[0], vy[1], vy[2], vy[3]);
+                reinterpret_cast<float4*>(lat + (size_t)b * N)[i] = make_float4(vl[0], vl[1], vl[2], vl[3]);
+                if (up_lc) reinterpret_cast<float4*>(upc + (size_t)b * N)[i] = make_float4(c1[0], c1[1], c1[2], c1[3]);
+                if (lat_lc) reinterpret_cast<float4*>(latc + (size_t)b * N)[i] = make_float4(c2[0], c2[1], c2[2], c2[3]);
+            } else {
+                ox[i] = vx[0]; oy[i] = vy[0]; lat[(size_t)b * N + i] = vl[0];
+                if (up_lc) upc[(size_t)b * N + i] = c1[0];
+                if (lat_lc) latc[(size_t)b * N + i] = c2[0];
+            }
+        }
+    }
+}
+
 inline dim3 grid1(int n) { return dim3((n + 127) / 128); }
 
 }  // namespace
@@ -506,6 +559,19 @@ hipError_t launch_pblock_from_params(const SolveCtx& c, const float* d_cam, cons
     GCLM_L(pblock_from_params_kernel, c.B, s, c, d_cam, d_grav, as_rpf, out);
     return hipGetLastError();
 }
+hipError_t launch_pack_fields(const float* up_raw, const float* up_lc, const float* lat_raw, const float* lat_lc,
+                              int B, int H, int W, bool vec4, float* up, float* upc, float* lat, float* latc,
+                              hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    const size_t N = (size_t)H * W;
+    const size_t units = vec4 ? N / 4 : N;
+    const int bx = (int)((units + 255) / 256 < 128 ? (units + 255) / 256 : 128);
+    const dim3 grid(bx, B < 4096 ? B : 4096), block(256);
+    if (vec4) hipLaunchKernelGGL(pack_fields_kernel<4>, grid, block, 0, s, up_raw, up_lc, lat_raw, lat_lc, B, N, up, upc, lat, latc);
+    else hipLaunchKernelGGL(pack_fields_kernel<1>, grid, block, 0, s, up_raw, up_lc, lat_raw, lat_lc, B, N, up, upc, lat, latc);
+    return hipGetLastError();
+}
+
 hipError_t launch_synth(int camera_model, uint64_t seed, int64_t first_index, int B, int H, int W, float sigma,
                         int group_size, int run, int run_stride, float* up, float* lat, float* upc, float* latc, float* gt_cam, float* gt_grav,
                         hipStream_t s) {

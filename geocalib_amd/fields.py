@@ -1,0 +1,49 @@
+"""The step before the LM path: CNN-head epilogue fused into one HIP pass (gclm_pack_fields).
+
+Replaces the tail of the reference's UpDecoder / LatitudeDecoder (geocalib/geocalib.py:57,73-75):
+
+    up_field            = F.normalize(up_raw, dim=1)
+    up_confidence       = sigmoid(up_log_confidence)
+    latitude_field      = asin(clamp(tanh(lat_raw), -1 + 1e-5, 1 - 1e-5))
+    latitude_confidence = sigmoid(lat_log_confidence)
+
+and writes the five planes in the layout LMOptimizer reads (eager PyTorch: 8 kernels, ~18 plane passes)."""
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+
+
+def pack_fields(up_raw: torch.Tensor, lat_raw: torch.Tensor, up_log_confidence: Optional[torch.Tensor] = None,
+                lat_log_confidence: Optional[torch.Tensor] = None, inplace: bool = False) -> Dict[str, torch.Tensor]:
+    """up_raw (B,2,H,W), lat_raw (B,1,H,W), log-confidences (B,H,W) or (B,1,H,W): raw head outputs on a HIP device.
+    Returns the dict `LMOptimizer.forward` consumes."""
+    for t in (up_raw, lat_raw):
+        if not t.is_cuda:
+            raise RuntimeError("geocalib_amd.pack_fields needs HIP device tensors (no CPU fallback)")
+    B, _, H, W = lat_raw.shape
+    assert up_raw.shape == (B, 2, H, W), up_raw.shape
+
+    def prep(t):
+        return None if t is None else t.detach().to(torch.float32).contiguous()
+
+    up_raw, lat_raw, ulc, llc = prep(up_raw), prep(lat_raw), prep(up_log_confidence), prep(lat_log_confidence)
+    for c in (ulc, llc):
+        assert c is None or c.numel() == B * H * W, c.shape
+    out_like = (lambda t: t) if inplace else torch.empty_like
+    up, lat = out_like(up_raw), out_like(lat_raw)
+    upc = None if ulc is None else out_like(ulc).view(B, H, W)
+    latc = None if llc is None else out_like(llc).view(B, H, W)
+    p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    with torch.cuda.device(lat_raw.device):
+        rc = _lib.load().gclm_pack_fields(p(up_raw), p(ulc), p(lat_raw), p(llc), B, H, W, p(up), p(upc), p(lat), p(latc),
+                                          torch.cuda.current_stream(lat_raw.device).cuda_stream)
+    if rc != 0:
+        raise _lib.GclmError(f"gclm_pack_fields failed ({rc})")
+    out = {"up_field": up, "latitude_field": lat}
+    if upc is not None:
+        out["up_confidence"] = upc
+    if latc is not None:
+        out["latitude_confidence"] = latc
+    return out

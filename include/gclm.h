@@ -164,6 +164,18 @@ int gclm_shared_apply(gclm_handle* h, int step, const float* d_partials, void* s
 int gclm_shared_finish(gclm_handle* h, float* d_info_out, void* stream);
 
 /*
+ * The step BEFORE the path: the CNN head epilogues UpDecoder / LatitudeDecoder (geocalib/geocalib.py:57,73-75)
+ * fused into one pass that writes the planes gclm_calibrate reads:
+ *   up = normalize(up_raw, dim=1)  (eps 1e-12),   latitude = asin(clamp(tanh(lat_raw), +-(1 - 1e-5))),
+ *   up_conf = sigmoid(up_logconf),                lat_conf = sigmoid(lat_logconf)     (NULL: skipped)
+ * Shapes: up_raw / up (B,2,H,W); lat_raw / lat (B,1,H,W); log-confidences / confidences (B,H,W).  In-place
+ * operation (output pointer == input pointer) is allowed.
+ */
+int gclm_pack_fields(const float* d_up_raw, const float* d_up_logconf, const float* d_lat_raw,
+                     const float* d_lat_logconf, int B, int H, int W, float* d_up, float* d_up_conf, float* d_lat,
+                     float* d_lat_conf, void* stream);
+
+/*
  * Measurement helper (bench.py, tests): synthetic perspective fields generated on the device,
  * SURVEY.md section 8(d).  Image i depends on (seed, first_index + i) only, so every sharding of
  * a batch sees identical data.  Writes the 5 planes and the ground truth (B,8) / (B,3).

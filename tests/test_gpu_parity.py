@@ -381,3 +381,35 @@ def test_hip_matches_reference_siclib_knobs(dev, model, knob):
         init = run({**conf, "num_steps": 0}, data_for(model, "bench"), dev)
         assert np.allclose(init["camera"], ref["init_camera"], rtol=5e-6)
         assert np.allclose(init["gravity"], ref["init_gravity"], atol=5e-6)
+
+
+@pytest.mark.parametrize("shape", [(3, 96, 128), (2, 33, 47)])
+@pytest.mark.parametrize("conf", [True, False])
+def test_pack_fields_matches_torch_head_epilogue(dev, shape, conf):
+    """gclm_pack_fields against the plain-PyTorch fp32 expression of the reference's head epilogues
+    (geocalib/geocalib.py:57,73-75), vectorised and scalar paths, with and without confidences, in place too."""
+    from geocalib_amd.fields import pack_fields
+    B, H, W = shape
+    g = torch.Generator().manual_seed(0)
+    up_raw = (torch.randn(B, 2, H, W, generator=g) * 3).to(dev)
+    lat_raw = (torch.randn(B, 1, H, W, generator=g) * 2).to(dev)
+    ulc = torch.randn(B, H, W, generator=g).to(dev) if conf else None
+    llc = torch.randn(B, 1, H, W, generator=g).to(dev) if conf else None
+    up_raw[0, :, 0, 0] = 0                                   # F.normalize eps path
+    ref = {"up_field": torch.nn.functional.normalize(up_raw, dim=1),
+           "latitude_field": torch.asin(torch.clamp(torch.tanh(lat_raw), -1 + 1e-5, 1 - 1e-5))}
+    if conf:
+        ref |= {"up_confidence": torch.sigmoid(ulc), "latitude_confidence": torch.sigmoid(llc[:, 0])}
+    out = pack_fields(up_raw, lat_raw, ulc, llc)
+    assert set(out) == set(ref)
+    for k in ref:
+        assert out[k].shape == ref[k].shape, k
+        assert torch.allclose(out[k], ref[k], atol=2e-6, rtol=2e-6), (k, (out[k] - ref[k]).abs().max().item())
+    inp = pack_fields(up_raw.clone(), lat_raw.clone(), None if ulc is None else ulc.clone(),
+                      None if llc is None else llc.clone(), inplace=True)
+    for k in ref:
+        assert torch.equal(inp[k], out[k]), k
+    # and the packed planes feed the optimiser directly
+    from geocalib_amd import LMOptimizer
+    res = LMOptimizer({"num_steps": 3, "early_stop": False}).eval()(out)
+    assert torch.isfinite(res["camera"]._data).all()
