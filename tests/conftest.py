@@ -16,6 +16,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Build the native pieces if a checkout has none yet (hipcc cross-compiles without a GPU)."""
+    lib = os.path.join(ROOT, "geocalib_amd", "lib", "libgeocalib_hip.so")
+    orc = os.path.join(ROOT, "oracle", "_build", "liblm_oracle_f32.so")
+    if not (os.path.exists(lib) and os.path.exists(orc)):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
 def pytest_collection_modifyitems(config, items):
     """`-m gpu` tests must never run (and silently pass) without a device."""
     try:
