@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libgeocalib_hip.so")
 CAMERA_MODEL_IDS = {"pinhole": 0, "simple_radial": 1, "radial": 2, "simple_divisional": 3}
 INFO_STRIDE = 48
 SHARED_PARTIAL_STRIDE = 16
+COMM_ID_BYTES = 128
 MAX_PARAMS = 5
 INFO = {"stop_at": 0, "initial_up_cost": 1, "initial_latitude_cost": 2, "initial_cost": 3,
         "final_up_cost": 4, "final_latitude_cost": 5, "final_cost": 6, "roll_uncertainty": 7,
@@ -63,6 +64,12 @@ _SIGNATURES = {
                                     _P, _P, _P, _P, _P, _P, _P]),
     "gclm_synth_fields_grouped": (C.c_int, [C.c_int, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float,
                                             C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "gclm_comm_unique_id": (C.c_int, [_P]),
+    "gclm_comm_create": (C.c_int, [C.POINTER(_P), _P, C.c_int, C.c_int, C.c_int]),
+    "gclm_comm_destroy": (C.c_int, [_P]),
+    "gclm_comm_last_error": (C.c_char_p, [_P]),
+    "gclm_comm_all_gather": (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
+    "gclm_comm_all_reduce_sum": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "gclm_set_timing": (C.c_int, [_P, C.c_int]),
     "gclm_last_pass_timing": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
 }

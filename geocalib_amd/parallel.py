@@ -57,6 +57,65 @@ def all_gather_rows(rows: torch.Tensor, n_total: int, group=None) -> torch.Tenso
     return torch.cat(parts, 0)
 
 
+class RcclComm:
+    """Direct RCCL communicator behind the C ABI (gclm_comm_*): the torch-free route to the two collectives.
+
+    The 128-byte unique id is created on rank 0 and must reach the other ranks out of band; `from_torch_group`
+    ships it over an existing torch.distributed group (any backend), `unique_id()` + the constructor let the
+    caller use a file or an environment variable instead."""
+
+    def __init__(self, unique_id: bytes, nranks: int, rank: int, device: int):
+        assert len(unique_id) == _lib.COMM_ID_BYTES
+        self.nranks, self.rank, self.device = nranks, rank, device
+        self._ptr = _lib.C.c_void_p()
+        buf = _lib.C.create_string_buffer(unique_id, _lib.COMM_ID_BYTES)
+        rc = _lib.load().gclm_comm_create(_lib.C.byref(self._ptr), buf, nranks, rank, device)
+        if rc != 0:
+            raise _lib.GclmError(f"gclm_comm_create failed ({rc}): {_lib.load().gclm_comm_last_error(None).decode()}")
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = _lib.C.create_string_buffer(_lib.COMM_ID_BYTES)
+        rc = _lib.load().gclm_comm_unique_id(buf)
+        if rc != 0:
+            raise _lib.GclmError(f"gclm_comm_unique_id failed ({rc})")
+        return buf.raw
+
+    @classmethod
+    def from_torch_group(cls, device: int, group=None) -> "RcclComm":
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls(box[0], world, rank, device)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise _lib.GclmError(f"{what} failed ({rc}): {_lib.load().gclm_comm_last_error(self._ptr).decode()}")
+
+    def all_gather(self, send: torch.Tensor) -> torch.Tensor:
+        """(n, k) float32 rows of every rank -> (nranks * n, k), rank order; ONE collective on the current stream."""
+        send = send.contiguous()
+        recv = send.new_empty((self.nranks * send.shape[0],) + tuple(send.shape[1:]))
+        s = torch.cuda.current_stream(send.device).cuda_stream
+        self._check(_lib.load().gclm_comm_all_gather(self._ptr, send.data_ptr(), recv.data_ptr(), send.numel(), s),
+                    "gclm_comm_all_gather")
+        return recv
+
+    def all_reduce_sum_(self, buf: torch.Tensor) -> torch.Tensor:
+        assert buf.is_contiguous() and buf.dtype == torch.float32
+        s = torch.cuda.current_stream(buf.device).cuda_stream
+        self._check(_lib.load().gclm_comm_all_reduce_sum(self._ptr, buf.data_ptr(), buf.numel(), s),
+                    "gclm_comm_all_reduce_sum")
+        return buf
+
+    def __del__(self):
+        try:
+            if self._ptr:
+                _lib.load().gclm_comm_destroy(self._ptr)
+        except Exception:
+            pass
+
+
 def infos_from_rows(opt: LMOptimizer, rows: torch.Tensor, has_up: bool) -> Dict[str, torch.Tensor]:
     cam, grav, info = unpack_rows(rows)
     out = {"camera": opt.camera_model(cam.contiguous()), "gravity": Gravity(grav.contiguous())}
@@ -65,7 +124,7 @@ def infos_from_rows(opt: LMOptimizer, rows: torch.Tensor, has_up: bool) -> Dict[
 
 
 def calibrate_sharded(opt: LMOptimizer, local_data: Dict[str, torch.Tensor], n_total: int,
-                      group=None) -> Dict[str, torch.Tensor]:
+                      group=None, comm: "RcclComm" = None) -> Dict[str, torch.Tensor]:
     """Solve this rank's shard (independent intrinsics) and all-gather everybody's results.
 
     `local_data` holds the fields of the images [shard_range(n_total, rank, world)) of the global
@@ -73,6 +132,9 @@ def calibrate_sharded(opt: LMOptimizer, local_data: Dict[str, torch.Tensor], n_t
     assert not opt.shared_intrinsics, "use SharedIntrinsicsSplit for shared intrinsics"
     out = opt(local_data)
     rows = pack_rows(*opt._last_raw)
+    if comm is not None and comm.nranks > 1:       # direct RCCL route (equal shards)
+        assert n_total % comm.nranks == 0, "the direct RCCL route expects equal shards"
+        return infos_from_rows(opt, comm.all_gather(rows), "up_field" in local_data)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         rows = all_gather_rows(rows, n_total, group)
         return infos_from_rows(opt, rows, "up_field" in local_data)
@@ -87,10 +149,10 @@ class SharedIntrinsicsSplit:
     (gclm_shared_reduce) -> ONE all-reduce(sum) of (num_groups, 16) floats -> solve + update
     (gclm_shared_apply)."""
 
-    def __init__(self, opt: LMOptimizer, num_groups: int, group=None):
+    def __init__(self, opt: LMOptimizer, num_groups: int, group=None, comm: "RcclComm" = None):
         assert opt.shared_intrinsics, "optimizer must be configured with shared_intrinsics=True"
         assert not opt.conf.early_stop, "split shared intrinsics runs a fixed number of steps"
-        self.opt, self.num_groups, self.group = opt, num_groups, group
+        self.opt, self.num_groups, self.group, self.comm = opt, num_groups, group, comm
 
     def __call__(self, local_data: Dict[str, torch.Tensor], group_of_frame: torch.Tensor):
         opt, lib = self.opt, _lib.load()
@@ -114,7 +176,9 @@ class SharedIntrinsicsSplit:
                            "gclm_shared_begin")
                 for step in range(opt.num_steps):
                     _lib.check(lib.gclm_shared_reduce(h.ptr, step, partials.data_ptr(), s), h.ptr, "gclm_shared_reduce")
-                    if multi:
+                    if self.comm is not None:
+                        self.comm.all_reduce_sum_(partials)
+                    elif multi:
                         dist.all_reduce(partials, op=dist.ReduceOp.SUM, group=self.group)
                     _lib.check(lib.gclm_shared_apply(h.ptr, step, partials.data_ptr(), s), h.ptr, "gclm_shared_apply")
                 _lib.check(lib.gclm_shared_finish(h.ptr, info.data_ptr(), s), h.ptr, "gclm_shared_finish")
@@ -124,4 +188,4 @@ class SharedIntrinsicsSplit:
 
 
 __all__ = ["shard_range", "pack_rows", "unpack_rows", "all_gather_rows", "calibrate_sharded",
-           "SharedIntrinsicsSplit", "ROW", "BaseCamera"]
+           "SharedIntrinsicsSplit", "RcclComm", "ROW", "BaseCamera"]

@@ -192,6 +192,23 @@ int gclm_synth_fields_grouped(int camera_model, uint64_t seed, int64_t first_ind
                               float* d_lat, float* d_up_conf, float* d_lat_conf, float* d_gt_cam,
                               float* d_gt_grav, void* stream);
 
+/*
+ * Multi-GPU collectives over RCCL / xGMI, one process per GPU (no reference counterpart: the
+ * reference's LM is single-process).  gclm_comm_unique_id is called on rank 0 only and its 128 bytes are handed to
+ * the other ranks by the caller.  Both collectives are asynchronous on `stream`.
+ *   gclm_comm_all_gather      the ONE gather of packed result rows (configs[2]); recv holds nranks * count floats
+ *   gclm_comm_all_reduce_sum  the ONE in-place sum of the (num_groups x GCLM_SHARED_PARTIAL_STRIDE) Schur partials
+ *                             per LM step between gclm_shared_reduce and gclm_shared_apply (configs[4])
+ */
+#define GCLM_COMM_ID_BYTES 128
+typedef struct gclm_comm gclm_comm;
+int gclm_comm_unique_id(void* id_out /* GCLM_COMM_ID_BYTES */);
+int gclm_comm_create(gclm_comm** out, const void* unique_id, int nranks, int rank, int device);
+int gclm_comm_destroy(gclm_comm* c);
+const char* gclm_comm_last_error(const gclm_comm* c);
+int gclm_comm_all_gather(gclm_comm* c, const float* d_send, float* d_recv, size_t count_per_rank, void* stream);
+int gclm_comm_all_reduce_sum(gclm_comm* c, float* d_buf, size_t count, void* stream);
+
 /* Timing helper: when enabled, every sweep launch is bracketed by HIP events on the solve's stream;
  * gclm_last_pass_timing waits for the recorded launches, returns their count and summed duration
  * since the previous read, and resets the record.  Returns <0 if timing was not enabled. */

@@ -413,3 +413,20 @@ def test_pack_fields_matches_torch_head_epilogue(dev, shape, conf):
     from geocalib_amd import LMOptimizer
     res = LMOptimizer({"num_steps": 3, "early_stop": False}).eval()(out)
     assert torch.isfinite(res["camera"]._data).all()
+
+
+def test_rccl_c_abi_single_rank(dev):
+    """gclm_comm_* (direct RCCL behind the C ABI) with a one-rank communicator: both collectives are the identity,
+    and the shared-intrinsics split driven through it equals the plain solve.  (Eight ranks are the driver's.)"""
+    from geocalib_amd import LMOptimizer
+    from geocalib_amd.parallel import RcclComm, SharedIntrinsicsSplit
+    comm = RcclComm(RcclComm.unique_id(), 1, 0, 0)
+    x = torch.arange(12, dtype=torch.float32, device=dev).reshape(4, 3)
+    assert torch.equal(comm.all_gather(x), x)
+    y = x.clone()
+    assert torch.equal(comm.all_reduce_sum_(y), x)
+    conf, d = conf_for("shared_pinhole", "bench"), data_for("shared_pinhole", "bench")
+    single = run(conf, d, dev)
+    out = to_np(SharedIntrinsicsSplit(LMOptimizer(conf).eval(), 1, comm=comm)(to_dev(d, dev), torch.zeros(4, dtype=torch.int32)))
+    assert np.array_equal(out["camera"], single["camera"]) and np.array_equal(out["gravity"], single["gravity"])
+    torch.cuda.synchronize()
