@@ -1,4 +1,12 @@
-"""Unit gravity direction in the camera frame (API of the reference's geocalib/gravity.py:12-131)."""
+"""Unit gravity direction in the camera frame.
+
+API-compatible with the reference's `geocalib.gravity.Gravity` (gravity.py:12-131): construction from a
+3-vector or from (roll, pitch), the `x / y / z / roll / pitch / rp / R` views, the (roll, pitch) Jacobians
+and the manifold update.  The angle conventions are the reference's:
+    g = (-sin r cos p, -cos r cos p, sin p),   pitch = asin(g_z),
+    roll = asin(-g_x / (sqrt(1 - g_z^2) + 1e-4)), mirrored to (-pi, pi] when g_y >= 0.
+The same expressions run on the device in csrc/gclm_device.h (grav_roll, grav_pitch, tangent_rp, from_rp).
+"""
 import math
 
 import torch
@@ -8,10 +16,18 @@ from .misc import EuclideanManifold, SphericalManifold, TensorWrapper, autocast
 from .utils import rad2rotmat
 
 
-class Gravity(TensorWrapper):
-    """(..., 3) unit vectors; roll / pitch are derived views."""
+def _as_tensor(v):
+    return v if isinstance(v, torch.Tensor) else torch.tensor(v)
 
-    eps = 1e-4
+
+def _component(index: int, doc: str):
+    return property(lambda self: self._data[..., index], doc=doc)
+
+
+class Gravity(TensorWrapper):
+    """(..., 3) unit vectors."""
+
+    eps = 1e-4        # regulariser of the roll denominator
 
     @autocast
     def __init__(self, data: torch.Tensor) -> None:
@@ -20,68 +36,69 @@ class Gravity(TensorWrapper):
 
     @classmethod
     def from_rp(cls, roll, pitch) -> "Gravity":
-        roll = roll if isinstance(roll, torch.Tensor) else torch.tensor(roll)
-        pitch = pitch if isinstance(pitch, torch.Tensor) else torch.tensor(pitch)
-        cp = pitch.cos()
-        return cls(torch.stack([-roll.sin() * cp, -roll.cos() * cp, pitch.sin()], dim=-1))
+        """Gravity of a camera rolled by `roll` and pitched by `pitch` (radians)."""
+        r, p = _as_tensor(roll), _as_tensor(pitch)
+        horizontal = -torch.cos(p)
+        return cls(torch.stack([torch.sin(r) * horizontal, torch.cos(r) * horizontal, torch.sin(p)], dim=-1))
 
-    @property
-    def vec3d(self) -> torch.Tensor:
-        return self._data
+    vec3d = property(lambda self: self._data, doc="The (..., 3) unit vector itself.")
+    x = _component(0, "First component.")
+    y = _component(1, "Second component.")
+    z = _component(2, "Third component.")
 
-    @property
-    def x(self) -> torch.Tensor:
-        return self._data[..., 0]
-
-    @property
-    def y(self) -> torch.Tensor:
-        return self._data[..., 1]
-
-    @property
-    def z(self) -> torch.Tensor:
-        return self._data[..., 2]
+    # ---- angles
+    def _angles(self):
+        gx, gy, gz = self._data.unbind(-1)
+        front = torch.asin(-gx / (torch.sqrt(1 - gz * gz) + self.eps))
+        back = -front - math.pi * torch.sign(gx)          # pointing "up" in the image: mirror
+        return torch.where(gy < 0, front, back), torch.asin(gz)
 
     @property
     def roll(self) -> torch.Tensor:
-        """Roll in (-pi, pi]; the eps in the denominator is the reference's (gravity.py:65)."""
-        r = torch.asin(-self.x / (torch.sqrt(1 - self.z**2) + self.eps))
-        return torch.where(self.y < 0, r, -r - math.pi * torch.sign(self.x))
+        return self._angles()[0]
 
     @property
     def pitch(self) -> torch.Tensor:
-        return torch.asin(self.z)
+        return self._angles()[1]
 
     @property
     def rp(self) -> torch.Tensor:
-        return torch.stack([self.roll, self.pitch], dim=-1)
-
-    def J_roll(self) -> torch.Tensor:
-        r, p = self.roll, self.pitch
-        return torch.stack([-r.cos() * p.cos(), r.sin() * p.cos(), torch.zeros_like(r)], -1)
-
-    def J_pitch(self) -> torch.Tensor:
-        r, p = self.roll, self.pitch
-        return torch.stack([r.sin() * p.sin(), r.cos() * p.sin(), p.cos()], -1)
-
-    def J_rp(self) -> torch.Tensor:
-        """d(vec3d)/d(roll, pitch), shape (..., 3, 2)."""
-        return torch.stack([self.J_roll(), self.J_pitch()], dim=-1)
+        return torch.stack(self._angles(), dim=-1)
 
     @property
     def R(self) -> torch.Tensor:
-        return rad2rotmat(roll=self.roll, pitch=self.pitch)
+        roll, pitch = self._angles()
+        return rad2rotmat(roll=roll, pitch=pitch)
+
+    # ---- derivatives
+    def J_rp(self) -> torch.Tensor:
+        """d(vec3d)/d(roll, pitch) as (..., 3, 2): columns (-cr cp, sr cp, 0) and (sr sp, cr sp, cp)."""
+        roll, pitch = self._angles()
+        sr, cr, sp, cp = roll.sin(), roll.cos(), pitch.sin(), pitch.cos()
+        d_roll = torch.stack([-cr * cp, sr * cp, torch.zeros_like(cp)], dim=-1)
+        d_pitch = torch.stack([sr * sp, cr * sp, cp], dim=-1)
+        return torch.stack([d_roll, d_pitch], dim=-1)
+
+    def J_roll(self) -> torch.Tensor:
+        return self.J_rp()[..., 0]
+
+    def J_pitch(self) -> torch.Tensor:
+        return self.J_rp()[..., 1]
 
     def J_R(self) -> torch.Tensor:
         raise NotImplementedError
 
+    # ---- manifold step
     def update(self, delta: torch.Tensor, spherical: bool = False) -> "Gravity":
+        """Apply a 2-vector step: on the sphere (Householder retraction) or on (roll, pitch)."""
         if spherical:
-            return self.__class__(SphericalManifold.plus(self.vec3d, delta))
-        rp = EuclideanManifold.plus(self.rp, delta)
-        return self.from_rp(rp[..., 0], rp[..., 1])
+            return type(self)(SphericalManifold.plus(self._data, delta))
+        stepped = EuclideanManifold.plus(self.rp, delta)
+        return self.from_rp(*stepped.unbind(-1))
 
     def J_update(self, spherical: bool = False) -> torch.Tensor:
-        return (SphericalManifold if spherical else EuclideanManifold).J_plus(self.vec3d)
+        manifold = SphericalManifold if spherical else EuclideanManifold
+        return manifold.J_plus(self._data)
 
     def __repr__(self):
-        return f"{self.__class__.__name__} {self.shape} {self.dtype} {self.device}"
+        return f"{type(self).__name__} {self.shape} {self.dtype} {self.device}"

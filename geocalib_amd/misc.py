@@ -29,81 +29,32 @@ def autocast(method):
 
 
 class TensorWrapper:
-    """A tensor whose last dimension is a record; everything before it is the batch shape."""
+    """A tensor whose last dimension is a record; everything before it is the batch shape.
+
+    Same surface as the reference's TensorWrapper (misc.py:50-154).  Tensor methods that keep the record
+    dimension (`to`, `cpu`, `float`, `unsqueeze`, ...) are forwarded to the wrapped tensor and re-wrapped;
+    the `new_*` factories are forwarded as they are."""
 
     _data = None
+    _REWRAPPED = ("to", "cpu", "cuda", "pin_memory", "float", "double", "detach", "unsqueeze", "squeeze")
+    _FACTORIES = ("new_tensor", "new_zeros", "new_ones", "new_full", "new_empty")
 
     @autocast
     def __init__(self, data: torch.Tensor):
         self._data = data
 
-    # ---- views of the underlying tensor
-    @property
-    def shape(self):
-        return self._data.shape[:-1]
-
-    @property
-    def device(self):
-        return self._data.device
-
-    @property
-    def dtype(self):
-        return self._data.dtype
+    shape = property(lambda self: self._data.shape[:-1], doc="Batch shape (record dimension dropped).")
+    device = property(lambda self: self._data.device)
+    dtype = property(lambda self: self._data.dtype)
 
     def __getitem__(self, index):
-        return self.__class__(self._data[index])
+        return type(self)(self._data[index])
 
     def __setitem__(self, index, item):
         self._data[index] = item.data
 
-    def _map(self, fn):
-        return self.__class__(fn(self._data))
-
-    def to(self, *args, **kwargs):
-        return self._map(lambda t: t.to(*args, **kwargs))
-
-    def cpu(self):
-        return self._map(torch.Tensor.cpu)
-
-    def cuda(self):
-        return self._map(torch.Tensor.cuda)
-
-    def pin_memory(self):
-        return self._map(torch.Tensor.pin_memory)
-
-    def float(self):
-        return self._map(torch.Tensor.float)
-
-    def double(self):
-        return self._map(torch.Tensor.double)
-
-    def detach(self):
-        return self._map(torch.Tensor.detach)
-
-    def unsqueeze(self, *args, **kwargs):
-        return self._map(lambda t: t.unsqueeze(*args, **kwargs))
-
-    def squeeze(self, *args, **kwargs):
-        return self._map(lambda t: t.squeeze(*args, **kwargs))
-
     def numpy(self):
         return self._data.detach().cpu().numpy()
-
-    # ---- factories on the same dtype / device
-    def new_tensor(self, *args, **kwargs):
-        return self._data.new_tensor(*args, **kwargs)
-
-    def new_zeros(self, *args, **kwargs):
-        return self._data.new_zeros(*args, **kwargs)
-
-    def new_ones(self, *args, **kwargs):
-        return self._data.new_ones(*args, **kwargs)
-
-    def new_full(self, *args, **kwargs):
-        return self._data.new_full(*args, **kwargs)
-
-    def new_empty(self, *args, **kwargs):
-        return self._data.new_empty(*args, **kwargs)
 
     @classmethod
     def stack(cls, objects, dim=0, *, out=None):
@@ -114,6 +65,28 @@ class TensorWrapper:
         if func is torch.stack:
             return cls.stack(*args, **(kwargs or {}))
         return NotImplemented
+
+
+def _rewrapped(name):
+    def method(self, *args, **kwargs):
+        return type(self)(getattr(self._data, name)(*args, **kwargs))
+    method.__name__ = name
+    method.__doc__ = f"`torch.Tensor.{name}` on the wrapped tensor, wrapped again."
+    return method
+
+
+def _factory(name):
+    def method(self, *args, **kwargs):
+        return getattr(self._data, name)(*args, **kwargs)
+    method.__name__ = name
+    method.__doc__ = f"`torch.Tensor.{name}` with the wrapper's dtype and device."
+    return method
+
+
+for _name in TensorWrapper._REWRAPPED:
+    setattr(TensorWrapper, _name, _rewrapped(_name))
+for _name in TensorWrapper._FACTORIES:
+    setattr(TensorWrapper, _name, _factory(_name))
 
 
 class EuclideanManifold:
