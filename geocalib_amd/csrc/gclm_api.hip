@@ -144,6 +144,7 @@ int timed_sweep(gclm_handle* h, const SweepArgs& a, hipStream_t s) {
 int check_shapes(gclm_handle* h, const float* lat, int B, int H, int W) {
     if (!lat) return fail(h, -3, "latitude_field is required (lm_optimizer.py:31 raises KeyError without it)");
     if (B < 0 || H <= 0 || W <= 0) return fail(h, -3, "bad shape B=%d H=%d W=%d", B, H, W);
+    if (B > 65535) return fail(h, -3, "batch %d exceeds 65535 images per call (grid.y): split the batch", B);
     if ((size_t)H * W >= (size_t)1 << 30) return fail(h, -3, "image too large");
     return 0;
 }
