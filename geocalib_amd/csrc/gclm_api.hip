@@ -425,6 +425,12 @@ int gclm_shared_finish(gclm_handle* h, float* d_info_out, void* stream) {
     return 0;
 }
 
+int gclm_upsample_fields(const float* d_src, int planes, int h, int w, int H, int W, float* d_dst, void* stream) {
+    if (!d_src || !d_dst || planes < 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return -3;
+    hipError_t e = launch_upsample(d_src, planes, h, w, H, W, d_dst, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : -10;
+}
+
 int gclm_pack_fields(const float* d_up_raw, const float* d_up_logconf, const float* d_lat_raw,
                      const float* d_lat_logconf, int B, int H, int W, float* d_up, float* d_up_conf, float* d_lat,
                      float* d_lat_conf, void* stream) {

@@ -511,6 +511,28 @@ __global__ void pack_fields_kernel(const float* __restrict__ up_raw, const float
     }
 }
 
+// ---------------------------------------------------------------- _post_process (the step after the path)
+// GeoCalib._post_process (extractor.py:51-69) brings the fields back to the input resolution with
+// F.interpolate(mode="bilinear", align_corners=False); one launch for any number of (h, w) planes.
+// Source index as in ATen (area_pixel_compute_source_index): src = max(0, (dst + 0.5) * in/out - 0.5).
+__global__ void upsample_bilinear_kernel(const float* __restrict__ src, int planes, int h, int w, int H, int W,
+                                         float* __restrict__ dst) {
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    const size_t total = (size_t)planes * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int X = (int)(i % W), Y = (int)((i / W) % H);
+        const size_t p = i / ((size_t)W * H);
+        const float fy = fmaxf(((float)Y + 0.5f) * sy - 0.5f, 0.f), fx = fmaxf(((float)X + 0.5f) * sx - 0.5f, 0.f);
+        const int y0 = min((int)fy, h - 1), x0 = min((int)fx, w - 1);
+        const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float* s = src + p * (size_t)h * w;
+        const float top = s[(size_t)y0 * w + x0] * (1.f - lx) + s[(size_t)y0 * w + x1] * lx;
+        const float bot = s[(size_t)y1 * w + x0] * (1.f - lx) + s[(size_t)y1 * w + x1] * lx;
+        dst[i] = top * (1.f - ly) + bot * ly;
+    }
+}
+
 inline dim3 grid1(int n) { return dim3((n + 127) / 128); }
 
 }  // namespace
@@ -559,6 +581,14 @@ hipError_t launch_pblock_from_params(const SolveCtx& c, const float* d_cam, cons
     GCLM_L(pblock_from_params_kernel, c.B, s, c, d_cam, d_grav, as_rpf, out);
     return hipGetLastError();
 }
+hipError_t launch_upsample(const float* src, int planes, int h, int w, int H, int W, float* dst, hipStream_t s) {
+    const size_t total = (size_t)planes * H * W;
+    if (total == 0) return hipSuccess;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(upsample_bilinear_kernel, dim3(blocks), dim3(256), 0, s, src, planes, h, w, H, W, dst);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_fields(const float* up_raw, const float* up_lc, const float* lat_raw, const float* lat_lc,
                               int B, int H, int W, bool vec4, float* up, float* upc, float* lat, float* latc,
                               hipStream_t s) {

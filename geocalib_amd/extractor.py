@@ -15,6 +15,7 @@ import torch.nn as nn
 from torch.nn.functional import interpolate
 
 from .camera import BaseCamera
+from .fields import upsample_fields
 from .lm_optimizer import LMOptimizer
 
 
@@ -46,12 +47,9 @@ class GeoCalib(nn.Module):
         """Undo scaling / cropping and bring the fields back to the input resolution."""
         camera = camera.undo_scale_crop(img_data)
         w, h = (int(v) for v in camera.size[0].round().tolist())
-        for k in ("latitude_field", "up_field"):
-            if k in out:
-                out[k] = interpolate(out[k], size=(h, w), mode="bilinear")
-        for k in ("up_confidence", "latitude_confidence"):
-            if k in out:
-                out[k] = interpolate(out[k][:, None], size=(h, w), mode="bilinear")[:, 0]
+        for k in ("latitude_field", "up_field", "up_confidence", "latitude_confidence"):
+            if k in out:      # bilinear, align_corners=False (extractor.py:60-63), one HIP launch per tensor
+                out[k] = upsample_fields(out[k], (h, w))
         zero = camera.new_zeros(camera.f.shape[0])
         out["focal_uncertainty"] = out.get("focal_uncertainty", zero) * (1.0 / img_data["scales"])[1]
         return camera, out

@@ -47,3 +47,21 @@ def pack_fields(up_raw: torch.Tensor, lat_raw: torch.Tensor, up_log_confidence: 
     if latc is not None:
         out["latitude_confidence"] = latc
     return out
+
+
+def upsample_fields(t: torch.Tensor, size) -> torch.Tensor:
+    """Bilinear resize of the trailing (h, w) planes of `t` to `size` = (H, W), matching
+    `torch.nn.functional.interpolate(t, size, mode="bilinear", align_corners=False)` (extractor.py:60-63)."""
+    if not t.is_cuda:
+        raise RuntimeError("geocalib_amd.upsample_fields needs a HIP device tensor (no CPU fallback)")
+    H, W = int(size[0]), int(size[1])
+    src = t.detach().to(torch.float32).contiguous()
+    h, w = src.shape[-2:]
+    dst = src.new_empty(src.shape[:-2] + (H, W))
+    planes = src.numel() // (h * w)
+    with torch.cuda.device(src.device):
+        rc = _lib.load().gclm_upsample_fields(src.data_ptr(), planes, h, w, H, W, dst.data_ptr(),
+                                              torch.cuda.current_stream(src.device).cuda_stream)
+    if rc != 0:
+        raise _lib.GclmError(f"gclm_upsample_fields failed ({rc})")
+    return dst

@@ -176,6 +176,13 @@ int gclm_pack_fields(const float* d_up_raw, const float* d_up_logconf, const flo
                      float* d_lat_conf, void* stream);
 
 /*
+ * The step AFTER the path: GeoCalib._post_process (geocalib/extractor.py:51-69) resizes the fields and confidences
+ * back to the input resolution with F.interpolate(mode="bilinear", align_corners=False).  `planes` = number of
+ * contiguous (h, w) planes in d_src (e.g. B*2 for the up field); d_dst holds planes x (H, W).
+ */
+int gclm_upsample_fields(const float* d_src, int planes, int h, int w, int H, int W, float* d_dst, void* stream);
+
+/*
  * Measurement helper (bench.py, tests): synthetic perspective fields generated on the device,
  * SURVEY.md section 8(d).  Image i depends on (seed, first_index + i) only, so every sharding of
  * a batch sees identical data.  Writes the 5 planes and the ground truth (B,8) / (B,3).

@@ -482,3 +482,44 @@ def test_randomised_configurations_against_oracle(dev, oracle):
         assert np.array_equal(out["camera"][:, [0, 1, 4, 5]], ref["camera"][:, [0, 1, 4, 5]])
     med = np.median(np.array(list(worst.values())), axis=0)
     assert med[0] < 2e-5 and med[1] < 2e-5 and med[3] < 2e-5, med
+
+
+@pytest.mark.parametrize("shape", [((2, 2, 24, 32), (61, 83)), ((3, 17, 23), (17, 23)), ((1, 1, 32, 48), (480, 720)), ((2, 40, 30), (20, 15))])
+def test_upsample_fields_matches_torch_interpolate(dev, shape):
+    """gclm_upsample_fields (GeoCalib._post_process, extractor.py:60-63) against F.interpolate bilinear."""
+    from geocalib_amd.fields import upsample_fields
+    src_shape, size = shape
+    x = torch.randn(*src_shape, generator=torch.Generator().manual_seed(1)).to(dev)
+    ref = torch.nn.functional.interpolate(x if x.dim() == 4 else x[:, None], size=size, mode="bilinear")
+    ref = ref if x.dim() == 4 else ref[:, 0]
+    out = upsample_fields(x, size)
+    assert out.shape == ref.shape
+    assert torch.allclose(out, ref, atol=2e-6, rtol=1e-6), (out - ref).abs().max().item()
+
+
+def test_calibrate_front_end(dev):
+    """GeoCalib.calibrate (extractor.py:72-127) with a stand-in field network: preprocessing bookkeeping,
+    LM on the HIP path, undo of scale / crop, fields resized back to the input resolution."""
+    from geocalib_amd import Gravity, camera_models, perspective_fields as pf
+    from geocalib_amd.extractor import GeoCalib
+    H0, W0 = 480, 700                                        # input image; preprocess -> 320 x 448 fields
+    cam = camera_models["pinhole"].from_dict({"height": torch.tensor([320.0]), "width": torch.tensor([448.0]),
+                                              "vfov": torch.tensor([0.9])})
+    grav = Gravity.from_rp(torch.tensor([0.15]), torch.tensor([-0.2]))
+
+    def field_model(img_data):
+        assert img_data["image"].shape[-2:] == (320, 448)
+        up, lat = pf.get_perspective_field(cam, grav)
+        ones = torch.ones(1, 320, 448)
+        return {"up_field": up.to(dev), "latitude_field": lat.to(dev), "up_confidence": ones.to(dev),
+                "latitude_confidence": ones.to(dev)}
+
+    model = GeoCalib(field_model).eval()
+    res = model.calibrate(torch.rand(3, H0, W0, device=dev))
+    assert res["up_field"].shape == (1, 2, H0, W0) and res["latitude_confidence"].shape == (1, H0, W0)
+    c = res["camera"]
+    assert c.size[0].tolist() == pytest.approx([W0, H0], abs=1e-3)
+    # the vertical field of view is invariant to the resize; the crop trims the width only
+    assert c.vfov.item() == pytest.approx(0.9, abs=2e-3)
+    assert torch.allclose(res["gravity"].vec3d.cpu(), grav.vec3d, atol=2e-3)
+    assert res["covariance"].shape == (1, 3, 3) and res["focal_uncertainty"].shape == (1,)
