@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libgeocalib_hip.so")
 
 CAMERA_MODEL_IDS = {"pinhole": 0, "simple_radial": 1, "radial": 2, "simple_divisional": 3}
 INFO_STRIDE = 48
-SHARED_PARTIAL_STRIDE = 16
+SHARED_PARTIAL_STRIDE = 32
 COMM_ID_BYTES = 128
 MAX_PARAMS = 5
 INFO = {"stop_at": 0, "initial_up_cost": 1, "initial_latitude_cost": 2, "initial_cost": 3,

@@ -60,8 +60,6 @@ int fail(gclm_handle* h, int code, const char* fmt, ...) {
 const char* validate(const gclm_config& c) {
     if (c.camera_model < GCLM_PINHOLE || c.camera_model > GCLM_SIMPLE_DIVISIONAL)
         return "camera_model: unknown (0 pinhole, 1 simple_radial, 2 radial, 3 simple_divisional)";
-    if (c.shared_intrinsics && c.camera_model == GCLM_RADIAL)
-        return "shared_intrinsics with the radial model (3 shared intrinsics) is not implemented by the HIP path";
     if (c.num_steps < 0 || c.num_steps > GCLM_MAX_STEPS) return "num_steps out of range [0, GCLM_MAX_STEPS]";
     if (!(c.up_loss_fn_scale > 0.f) || !(c.lat_loss_fn_scale > 0.f)) return "loss scales must be > 0";
     if (c.group_size < 0) return "group_size must be >= 0";

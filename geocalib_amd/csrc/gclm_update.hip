@@ -228,9 +228,9 @@ __global__ __launch_bounds__(kImgPerBlock * kSlots) void shared_frame_kernel(Sol
     if (step == 0) { s.init_cu = cu; s.init_cl = cl; }     // infos["initial_*"] (:585-588)
     cost_bookkeeping(c.cfg, c.ctrl, step, total, s, false);   // lambda is never updated (:612)
     c.state[step & 1][b] = s;
-    float4* out = reinterpret_cast<float4*>(c.frame_sys + (size_t)b * kNAcc);   // shared mode: <= 4 columns
-#pragma unroll
-    for (int q = 0; q < kNAcc / 4; ++q) out[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    const int nacc = acc_floats(c.cfg.camera_model);
+    float* out = c.frame_sys + (size_t)b * nacc;
+    for (int q = 0; q < nacc; ++q) out[q] = acc[q];
 }
 
 __device__ inline int lower_bound(const int32_t* a, int n, int key) {
@@ -247,9 +247,8 @@ __device__ inline void group_range(const SolveCtx& c, int g, int& f0, int& f1) {
 }
 
 // Damped 2x2 gravity block of a frame and its inverse; returns false if not positive definite.
-__device__ inline bool frame_block(const float* fs, float lambda, float (&Dinv)[2][2]) {
-    const float* h = fs + A_H00;
-    const float a = h[0] + fmaxf(h[0] * lambda, 1e-6f), b = h[1], d = h[4] + fmaxf(h[4] * lambda, 1e-6f);
+__device__ inline bool frame_block(const float (&Hf)[kMaxP][kMaxP], float lambda, float (&Dinv)[2][2]) {
+    const float a = Hf[0][0] + fmaxf(Hf[0][0] * lambda, 1e-6f), b = Hf[0][1], d = Hf[1][1] + fmaxf(Hf[1][1] * lambda, 1e-6f);
     const float det = a * d - b * b;
     if (!(a > 0.f) || !(det > 0.f)) return false;
     const float id = 1.0f / det;
@@ -257,80 +256,80 @@ __device__ inline bool frame_block(const float* fs, float lambda, float (&Dinv)[
     return true;
 }
 
-// per group: local Schur partials over this device's frames of the group
-//   layout (GCLM_SHARED_PARTIAL_STRIDE floats): [0..3] sum E^T Dinv E, [4..5] sum E^T Dinv g,
-//   [6..9] sum H_ii, [10..11] sum g_i, [12] #frames; NaN in [0] marks a non-PD frame block.
+// per group: local Schur partials over this device's frames of the group (ni = 1..3 shared intrinsics)
+//   layout (GCLM_SHARED_PARTIAL_STRIDE = 32 floats): [0..9) sum E^T Dinv E (3x3 row-major), [9..12) sum E^T Dinv g,
+//   [12..21) sum H_ii, [21..24) sum g_i, [24] #frames; NaN in [0] marks a non-PD frame block.
+constexpr int kNI = 3, kGS = 0, kGR = 9, kGC = 12, kGc = 21, kGN = 24;
 __global__ void shared_group_kernel(SolveCtx c, int step, float* gp) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= c.n_groups) return;
     if (c.cfg.early_stop && c.ctrl->stopped) return;
-    const int ni = c.cfg.camera_model == GCLM_PINHOLE ? 1 : 2;
+    const int ni = 1 + num_dist_params(c.cfg.camera_model), pm = acc_pm(c.cfg.camera_model);
+    const int nacc = acc_floats(c.cfg.camera_model);
     int f0, f1;
     group_range(c, g, f0, f1);
-    float S[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, r[2] = {0.f, 0.f}, C[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, cg[2] = {0.f, 0.f};
+    float S[kNI][kNI] = {}, r[kNI] = {}, C[kNI][kNI] = {}, cg[kNI] = {};
     bool ok = true;
     for (int f = f0; f < f1; ++f) {
-        const float* fs = c.frame_sys + (size_t)f * kNAcc;
         float Hf[kMaxP][kMaxP], Gf[kMaxP], Dinv[2][2];
-        unpack_system(fs, 4, Hf, Gf);
-        ok = frame_block(fs, c.state[step & 1][f].lambda, Dinv) && ok;
+        unpack_system(c.frame_sys + (size_t)f * nacc, pm, Hf, Gf);
+        ok = frame_block(Hf, c.state[step & 1][f].lambda, Dinv) && ok;
+        const float q0 = Dinv[0][0] * Gf[0] + Dinv[0][1] * Gf[1], q1 = Dinv[1][0] * Gf[0] + Dinv[1][1] * Gf[1];
         for (int i = 0; i < ni; ++i) {
-            // Dinv E[:, i]
-            const float e0 = Hf[0][2 + i], e1 = Hf[1][2 + i];
+            const float e0 = Hf[0][2 + i], e1 = Hf[1][2 + i];                         // E[:, i]
             const float t0 = Dinv[0][0] * e0 + Dinv[0][1] * e1, t1 = Dinv[1][0] * e0 + Dinv[1][1] * e1;
             for (int j = 0; j < ni; ++j) S[j][i] += Hf[0][2 + j] * t0 + Hf[1][2 + j] * t1;
-            const float q0 = Dinv[0][0] * Gf[0] + Dinv[0][1] * Gf[1], q1 = Dinv[1][0] * Gf[0] + Dinv[1][1] * Gf[1];
             r[i] += e0 * q0 + e1 * q1;
             cg[i] += Gf[2 + i];
             for (int j = 0; j < ni; ++j) C[i][j] += Hf[2 + i][2 + j];
         }
     }
     float* o = gp + (size_t)g * GCLM_SHARED_PARTIAL_STRIDE;
-    o[0] = ok ? S[0][0] : __builtin_nanf("");
-    o[1] = S[0][1]; o[2] = S[1][0]; o[3] = S[1][1];
-    o[4] = r[0]; o[5] = r[1];
-    o[6] = C[0][0]; o[7] = C[0][1]; o[8] = C[1][0]; o[9] = C[1][1];
-    o[10] = cg[0]; o[11] = cg[1];
-    o[12] = (float)(f1 - f0);
-    o[13] = o[14] = o[15] = 0.f;
+    for (int i = 0; i < GCLM_SHARED_PARTIAL_STRIDE; ++i) o[i] = 0.f;
+    for (int i = 0; i < ni; ++i) {
+        o[kGR + i] = r[i];
+        o[kGc + i] = cg[i];
+        for (int j = 0; j < ni; ++j) { o[kGS + i * kNI + j] = S[i][j]; o[kGC + i * kNI + j] = C[i][j]; }
+    }
+    if (!ok) o[0] = __builtin_nanf("");
+    o[kGN] = (float)(f1 - f0);
 }
 
 // per frame: solve the (tiny) Schur system of its group from the REDUCED partials (redundantly per
-// frame: ni <= 2), back-substitute its own gravity block, update (lm_optimizer.py:597-606).
+// frame: ni <= 3), back-substitute its own gravity block, update (lm_optimizer.py:597-606).
 __global__ void shared_apply_kernel(SolveCtx c, int step, const float* gp) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= c.B) return;
     if (c.cfg.early_stop && c.ctrl->stopped) return;
     const gclm_config& cfg = c.cfg;
-    const int ni = cfg.camera_model == GCLM_PINHOLE ? 1 : 2;
+    const int ni = 1 + num_dist_params(cfg.camera_model), pm = acc_pm(cfg.camera_model);
     const int g = c.group_of_frame ? c.group_of_frame[b] : b / c.group_size;
     State s = c.state[step & 1][b];
     const float* o = gp + (size_t)g * GCLM_SHARED_PARTIAL_STRIDE;
-    float A[2][2], dI[2] = {0.f, 0.f}, dG[2] = {0.f, 0.f};
+    float A[kNI][kNI], dI[kNI] = {}, dG[2] = {0.f, 0.f};
     bool ok = o[0] == o[0];
     for (int i = 0; i < ni; ++i) {
-        dI[i] = o[10 + i] - o[4 + i];
-        for (int j = 0; j < ni; ++j) A[i][j] = o[6 + 2 * i + j] - o[2 * i + j];
-        A[i][i] += fmaxf(o[6 + 2 * i + i] * s.lambda, 1e-6f);      // damping on sum H_ii (:123-126)
+        dI[i] = o[kGc + i] - o[kGR + i];
+        for (int j = 0; j < ni; ++j) A[i][j] = o[kGC + i * kNI + j] - o[kGS + i * kNI + j];
+        A[i][i] += fmaxf(o[kGC + i * kNI + i] * s.lambda, 1e-6f);      // damping on sum H_ii (:123-126)
     }
-    ok = ok && chol_solve<2>(ni, A, dI);
-    const float* fs = c.frame_sys + (size_t)b * kNAcc;
+    ok = ok && chol_solve<kNI>(ni, A, dI);
     float Hf[kMaxP][kMaxP], Gf[kMaxP], Dinv[2][2];
-    unpack_system(fs, 4, Hf, Gf);
-    ok = ok && frame_block(fs, s.lambda, Dinv);
+    unpack_system(c.frame_sys + (size_t)b * acc_floats(cfg.camera_model), pm, Hf, Gf);
+    ok = ok && frame_block(Hf, s.lambda, Dinv);
     if (ok) {
         float r0 = Gf[0], r1 = Gf[1];
         for (int i = 0; i < ni; ++i) { r0 -= Hf[0][2 + i] * dI[i]; r1 -= Hf[1][2 + i] * dI[i]; }
         dG[0] = Dinv[0][0] * r0 + Dinv[0][1] * r1;
         dG[1] = Dinv[1][0] * r0 + Dinv[1][1] * r1;
     } else {
-        dI[0] = dI[1] = 0.f;
+        for (int i = 0; i < kNI; ++i) dI[i] = 0.f;
         s.fails += 1.f;
     }
     const V3 gv = grav_update({s.gx, s.gy, s.gz}, dG[0], dG[1], cfg.use_spherical_manifold != 0);
     s.gx = gv.x; s.gy = gv.y; s.gz = gv.z;
     update_focal(s, dI[0], cfg.use_log_focal != 0);
-    if (ni == 2) update_dist(s, cfg.camera_model, dI[1], 0.f);
+    if (ni >= 2) update_dist(s, cfg.camera_model, dI[1], dI[2]);
     c.state[(step + 1) & 1][b] = s;
     PBlock p;
     build_pblock(s, cfg.use_spherical_manifold != 0, cfg.use_log_focal != 0, p);

@@ -149,12 +149,13 @@ int gclm_system(gclm_handle* h, const float* d_up, const float* d_lat, const flo
 /*
  * Shared-intrinsics solve with a group's frames split over several devices (BASELINE config 5).
  * The caller drives the LM loop: per step, gclm_shared_reduce leaves, for each of the G groups,
- * the local Schur partials [sum E^T D^-1 E (ni x ni) | sum E^T D^-1 g (ni) | sum H_ii (ni x ni) | sum g_i (ni)]
+ * the local Schur partials [sum E^T D^-1 E (3 x 3) | sum E^T D^-1 g (3) | sum H_ii (3 x 3) | sum g_i (3) | #frames]
+ * over its ni <= 3 shared intrinsics (unused entries zero)
  * in d_partials (G x GCLM_SHARED_PARTIAL_STRIDE floats); the caller all-reduces (sum) that buffer over the
  * ranks holding frames of the same groups (RCCL), then gclm_shared_apply solves and updates its frames.
  * Together they replace the dense arrow-head Cholesky of lm_optimizer.py:350-383,:597-603.
  */
-#define GCLM_SHARED_PARTIAL_STRIDE 16
+#define GCLM_SHARED_PARTIAL_STRIDE 32
 int gclm_shared_begin(gclm_handle* h, const float* d_up, const float* d_lat, const float* d_up_conf,
                       const float* d_lat_conf, int B_local, int H, int W, float* d_cam_io,
                       float* d_grav_io, const int32_t* d_group_of_frame /* (B_local), non-decreasing */,

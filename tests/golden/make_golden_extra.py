@@ -68,6 +68,14 @@ def main():
         for k, v in pack(out).items():
             extra[f"{model}/squared_loss/{k}"] = v
         print(model, "squared loss f", out["camera"]._data[:, 3].numpy())
+    # ---- shared intrinsics with the 5-parameter radial model (3 shared intrinsics)
+    inp = np.load(os.path.join(HERE, "inputs_radial.npz"))
+    data = {k: torch.from_numpy(inp[k]) for k in ("up_field", "latitude_field", "up_confidence", "latitude_confidence")}
+    with torch.no_grad():
+        out = ref.lm_optimizer.LMOptimizer({"camera_model": "radial", "shared_intrinsics": True, **BENCH}).eval()(data)
+    for k, v in pack(out).items():
+        extra[f"radial/shared/{k}"] = v
+    print("radial shared f", out["camera"]._data[:, 3].numpy(), "k", out["camera"]._data[0, 6:].numpy())
     np.savez_compressed(os.path.join(HERE, "golden_extra.npz"), **extra)
 
 

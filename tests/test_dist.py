@@ -98,30 +98,26 @@ def _schur_worker(rank, world, setname, q):
     sysm = lm_oracle.system(data, init["camera"], init["gravity"], conf, precision="f64")
     Hs, Gs, lam = sysm["H"], sysm["G"], 0.1
     lo, hi = shard_range(B, rank, world)
-    # local Schur partials, layout of gclm_update.hip::shared_group_kernel
-    part = np.zeros(16)
+    # local Schur partials, layout of gclm_update.hip::shared_group_kernel (stride 32, 3x3 blocks)
+    part = np.zeros(32)
     for b in range(lo, hi):
         Dinv = np.linalg.inv(_damped(Hs[b, :2, :2], lam))
         E = Hs[b, :2, 2:]
-        part[0:ni * ni] += (E.T @ Dinv @ E).ravel() if ni == 1 else 0
-        if ni == 2:
-            part[0:4] += (E.T @ Dinv @ E).ravel()
-        part[4:4 + ni] += E.T @ Dinv @ Gs[b, :2]
-        C = Hs[b, 2:, 2:]
-        if ni == 1:
-            part[6] += C[0, 0]
-        else:
-            part[6:10] += C.ravel()
-        part[10:10 + ni] += Gs[b, 2:]
+        S, C = np.zeros((3, 3)), np.zeros((3, 3))
+        S[:ni, :ni] = E.T @ Dinv @ E
+        C[:ni, :ni] = Hs[b, 2:, 2:]
+        part[0:9] += S.ravel()
+        part[9:9 + ni] += E.T @ Dinv @ Gs[b, :2]
+        part[12:21] += C.ravel()
+        part[21:21 + ni] += Gs[b, 2:]
+        part[24] += 1
     t = torch.from_numpy(part)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)                          # the ONE collective per step
     part = t.numpy()
-    if ni == 1:
-        S = np.array([[part[6] - part[0]]]) + np.diag(np.maximum(np.array([part[6]]) * lam, 1e-6))
-    else:
-        C = part[6:10].reshape(2, 2)
-        S = C - part[0:4].reshape(2, 2) + np.diag(np.maximum(np.diag(C) * lam, 1e-6))
-    dI = np.linalg.solve(S, part[10:10 + ni] - part[4:4 + ni])
+    assert part[24] == B
+    C = part[12:21].reshape(3, 3)[:ni, :ni]
+    S = C - part[0:9].reshape(3, 3)[:ni, :ni] + np.diag(np.maximum(np.diag(C) * lam, 1e-6))
+    dI = np.linalg.solve(S, part[21:21 + ni] - part[9:9 + ni])
     dG = np.stack([np.linalg.inv(_damped(Hs[b, :2, :2], lam)) @ (Gs[b, :2] - Hs[b, :2, 2:] @ dI) for b in range(lo, hi)])
     dense = _dense_arrowhead_delta(Hs, Gs, lam, ni)
     assert np.allclose(dI, dense[2 * B:], rtol=1e-9, atol=1e-12)

@@ -523,3 +523,13 @@ def test_calibrate_front_end(dev):
     assert c.vfov.item() == pytest.approx(0.9, abs=2e-3)
     assert torch.allclose(res["gravity"].vec3d.cpu(), grav.vec3d, atol=2e-3)
     assert res["covariance"].shape == (1, 3, 3) and res["focal_uncertainty"].shape == (1,)
+
+
+def test_hip_matches_reference_shared_radial(dev):
+    """Shared intrinsics with the 5-parameter radial model: 3x3 Schur complement vs the reference's dense solve."""
+    g = np.load(os.path.join(GOLDEN, "golden_extra.npz"))
+    ref = {k.split("/", 2)[2]: g[k] for k in g.files if k.startswith("radial/shared/")}
+    conf = {"camera_model": "radial", "shared_intrinsics": True, "num_steps": 20, "early_stop": False}
+    out = run(conf, data_for("radial", "bench"), dev)
+    compare_result(out, ref, {**TOL, "cost": 5e-4, "unc": 5e-3, "cov": 5e-3}, "radial/shared")
+    assert np.abs(out["camera"][:, 6:] - out["camera"][0, 6:]).max() < 1e-6      # one (k1, k2) for the group

@@ -149,3 +149,12 @@ def test_oracle_matches_reference_siclib_knobs(oracle, model, knob):
         init = oracle.solve(data_for(model, "bench"), {**conf, "num_steps": 0}, precision="f32")
         assert np.allclose(init["camera"], ref["init_camera"], rtol=2e-6)
         assert np.allclose(init["gravity"], ref["init_gravity"], atol=2e-6)
+
+
+def test_oracle_matches_reference_shared_radial(oracle):
+    """Shared intrinsics with three shared parameters (f, k1, k2): the dense arrow-head path of the reference."""
+    g = np.load(os.path.join(GOLDEN, "golden_extra.npz"))
+    ref = {k.split("/", 2)[2]: g[k] for k in g.files if k.startswith("radial/shared/")}
+    conf = {"camera_model": "radial", "shared_intrinsics": True, "num_steps": 20, "early_stop": False}
+    out = oracle.solve(data_for("radial", "bench"), conf, precision="f32")
+    compare_result(out, ref, {**TIGHT, "cost": 2e-4, "cov": 1e-3, "unc": 2e-3}, "radial/shared")
