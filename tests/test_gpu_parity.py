@@ -533,3 +533,29 @@ def test_hip_matches_reference_shared_radial(dev):
     out = run(conf, data_for("radial", "bench"), dev)
     compare_result(out, ref, {**TOL, "cost": 5e-4, "unc": 5e-3, "cov": 5e-3}, "radial/shared")
     assert np.abs(out["camera"][:, 6:] - out["camera"][0, 6:]).max() < 1e-6      # one (k1, k2) for the group
+
+
+def test_c_abi_from_plain_c(dev, tmp_path):
+    """examples/calibrate_c_abi.c: the library driven from C99 (gcc, no Python / torch in the process) must give
+    the same calibration as the Python host path on the same device-generated fields."""
+    import re
+    import subprocess
+    from conftest import ROOT
+    from geocalib_amd import LMOptimizer
+    exe = str(tmp_path / "calibrate_c_abi")
+    lib = os.path.join(ROOT, "geocalib_amd", "lib")
+    subprocess.run(["gcc", "-std=c99", "-D__HIP_PLATFORM_AMD__", os.path.join(ROOT, "examples", "calibrate_c_abi.c"),
+                    "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", "-L" + lib, "-lgeocalib_hip",
+                    "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath," + lib, "-o", exe],
+                   check=True, capture_output=True)
+    for model_id, model in ((0, "pinhole"), (1, "simple_radial")):
+        txt = subprocess.run([exe, str(model_id), "3", "120", "160"], check=True, capture_output=True, text=True).stdout
+        rows = re.findall(r"image \d+: f (\S+) \(gt (\S+)\) k1 (\S+) .*? g \((\S+) (\S+) (\S+)\)", txt)
+        assert len(rows) == 3, txt
+        data, gtc, _ = synth_device(model, 3, 120, 160, dev, seed=42)
+        out = to_np(LMOptimizer({"camera_model": model, "num_steps": 20, "early_stop": False}).eval()(data))
+        got = np.array(rows, dtype=np.float64)
+        assert np.allclose(got[:, 0], out["camera"][:, 3], rtol=2e-6), (got[:, 0], out["camera"][:, 3])
+        assert np.allclose(got[:, 1], gtc[:, 3].cpu().numpy(), rtol=2e-6)
+        assert np.allclose(got[:, 2], out["camera"][:, 6], atol=2e-5)
+        assert np.allclose(got[:, 3:6], out["gravity"], atol=2e-5)
