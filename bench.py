@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=1024, help="images per GPU")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
-    ap.add_argument("--camera-model", default="pinhole", choices=["pinhole", "simple_radial"])
+    ap.add_argument("--camera-model", default="pinhole", choices=["pinhole", "simple_radial", "radial", "simple_divisional"])
     ap.add_argument("--lm-steps", type=int, default=20)
     ap.add_argument("--shared-group", type=int, default=0,
                     help="frames per shared-intrinsics group (BASELINE configs[4]: 16); 0 = independent intrinsics. "
