@@ -81,8 +81,9 @@ __device__ inline V3 grav_update(V3 g, float d0, float d1, bool spherical) {
 // fx rebuilt from fy by the old ratio.
 __device__ inline void update_focal(State& s, float delta, bool as_log) {
     const float fy = as_log ? expf(logf(s.fy) + delta) : s.fy + delta;
-    const float min_f = s.h * 0.5f / tanf((150.f / 180.f * kPi) * 0.5f);
-    const float max_f = s.h * 0.5f / tanf((5.f / 180.f * kPi) * 0.5f);
+    // fov2focal(deg2rad(150), h), fov2focal(deg2rad(5), h) with the float32 values of tan(75 deg), tan(2.5 deg)
+    const float min_f = s.h * 0.5f / 3.7320504f;
+    const float max_f = s.h * 0.5f / 0.043660946f;
     const float fyc = fminf(fmaxf(fy, min_f), max_f);
     s.fx = fyc * s.fx / s.fy;
     s.fy = fyc;
@@ -109,59 +110,82 @@ __device__ inline void build_pblock(const State& s, bool spherical, bool log_foc
 }
 
 // ---------------------------------------------------------------- small dense algebra
+// Everything here has compile-time sizes and fully unrolled loops so that the tiny matrices live in
+// registers: a dynamically indexed local array is placed in scratch memory on gfx950 and made the
+// first generic version of the update kernel 2.5x slower (42 us vs 17 us per launch at B = 1024).
 
-// In-place Cholesky solve of an n x n SPD system (fp32 like torch.linalg.cholesky on fp32).
-template <int MAXN>
-__device__ inline bool chol_solve(int n, float (&A)[MAXN][MAXN], float* b) {
-    for (int j = 0; j < n; ++j) {
+// In-place Cholesky solve of an N x N SPD system (fp32 like torch.linalg.cholesky on fp32).
+template <int N>
+__device__ inline bool chol_solve(float (&A)[N][N], float (&b)[N]) {
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
         float s = A[j][j];
+#pragma unroll
         for (int k = 0; k < j; ++k) s -= A[j][k] * A[j][k];
-        if (!(s > 0.f)) return false;
+        ok = ok && (s > 0.f);
         const float l = sqrtf(s);
         A[j][j] = l;
-        for (int i = j + 1; i < n; ++i) {
+#pragma unroll
+        for (int i = j + 1; i < N; ++i) {
             float t = A[i][j];
+#pragma unroll
             for (int k = 0; k < j; ++k) t -= A[i][k] * A[j][k];
             A[i][j] = t / l;
         }
     }
-    for (int i = 0; i < n; ++i) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
         float t = b[i];
+#pragma unroll
         for (int k = 0; k < i; ++k) t -= A[i][k] * b[k];
         b[i] = t / A[i][i];
     }
-    for (int i = n - 1; i >= 0; --i) {
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
         float t = b[i];
-        for (int k = i + 1; k < n; ++k) t -= A[k][i] * b[k];
+#pragma unroll
+        for (int k = i + 1; k < N; ++k) t -= A[k][i] * b[k];
         b[i] = t / A[i][i];
     }
-    return true;
+    return ok;
 }
 
 // Symmetric PM x PM system (PM = 4 or 5 full columns d1,d2,f,k1[,k2]) out of an accumulator record.
-__device__ inline void unpack_system(const float* acc, int pm, float (&Hm)[kMaxP][kMaxP], float (&G)[kMaxP]) {
-    for (int i = 0; i < kMaxP; ++i) {
-        G[i] = i < pm ? acc[A_G0 + i] : 0.f;
-        for (int j = 0; j < kMaxP; ++j) Hm[i][j] = 0.f;
+template <int PM>
+__device__ inline void unpack_system(const float* acc, float (&Hm)[PM][PM], float (&G)[PM]) {
+#pragma unroll
+    for (int i = 0; i < PM; ++i) {
+        G[i] = acc[A_G0 + i];
+#pragma unroll
+        for (int j = i; j < PM; ++j) Hm[i][j] = Hm[j][i] = acc[acc_h(PM, i, j)];
     }
-    for (int i = 0; i < pm; ++i)
-        for (int j = i; j < pm; ++j) Hm[i][j] = Hm[j][i] = acc[acc_h(pm, i, j)];
 }
 
-// Column plan of calculate_gradient_and_hessian (lm_optimizer.py:335-344)
-struct Plan {
-    int n, cols[kMaxP];
-    int focal_dim, dist_dim;   // lm_optimizer.py:223-235 (python indices into delta)
-};
-__device__ inline Plan make_plan(const gclm_config& cfg) {
-    Plan p;
-    p.n = 0;
-    if (cfg.estimate_gravity) { p.cols[p.n++] = 0; p.cols[p.n++] = 1; }
-    if (cfg.estimate_focal) p.cols[p.n++] = 2;
-    for (int k = 0; k < num_dist_params(cfg.camera_model); ++k) p.cols[p.n++] = 3 + k;
-    p.focal_dim = cfg.estimate_focal ? (cfg.estimate_gravity ? 2 : 0) : -1;
-    p.dist_dim = p.focal_dim + 1;          // reproduces the prior_focal + distortion overlap (quirk)
-    return p;
+// Which of the PM full columns are free (calculate_gradient_and_hessian, lm_optimizer.py:335-344).  The
+// system is solved at its full size with the fixed columns replaced by identity rows -- arithmetically the
+// reference's sub-matrix solve (the masked entries only ever contribute exact zeros), without dynamic indexing.
+template <int PM>
+__device__ inline void active_columns(const gclm_config& cfg, bool (&act)[PM]) {
+    const int nd = num_dist_params(cfg.camera_model);
+#pragma unroll
+    for (int k = 0; k < PM; ++k)
+        act[k] = k < 2 ? cfg.estimate_gravity != 0 : (k == 2 ? cfg.estimate_focal != 0 : k - 3 < nd);
+}
+
+// The steps of update_estimate (lm_optimizer.py:518-549) out of the full-size solution, reproducing the python
+// index arithmetic of :223-235: dist_delta_dims start at focal_delta_dims[-1] + 1, which is 0 when the focal is a
+// prior -- i.e. the distortion then takes the GRAVITY steps (reference quirk, kept).
+template <int PM>
+__device__ inline void split_delta(const gclm_config& cfg, const float (&d)[PM], float& dg0, float& dg1, float& df,
+                                   float& dk1, float& dk2) {
+    const bool eg = cfg.estimate_gravity != 0, ef = cfg.estimate_focal != 0;
+    dg0 = eg ? d[0] : 0.f;
+    dg1 = eg ? d[1] : 0.f;
+    df = ef ? d[2] : 0.f;
+    const float d4 = PM > 4 ? d[PM - 1] : 0.f;
+    dk1 = (ef || !eg) ? d[3] : d[0];
+    dk2 = (ef || !eg) ? d4 : d[1];
 }
 
 // sum(c.mean(-1) for c in costs.values()) (lm_optimizer.py:584,610), float32
@@ -189,7 +213,8 @@ __device__ inline void cost_bookkeeping(const gclm_config& cfg, Ctrl* ctrl, int 
 
 // One LM step of one image from its reduced accumulator record: lambda rule + allclose bookkeeping,
 // damped normal equations over the estimated columns, manifold / focal / distortion update, next
-// parameter block.  (update_kernel body; also run by the last workgroup of an image in the fused sweep.)
+// parameter block.
+template <int PM>
 __device__ inline void update_image(const SolveCtx& c, int step, int b, const float (&acc)[kNAccMax]) {
     const gclm_config& cfg = c.cfg;
     State s = c.state[step & 1][b];
@@ -200,26 +225,28 @@ __device__ inline void update_image(const SolveCtx& c, int step, int b, const fl
     cost_bookkeeping(cfg, c.ctrl, step, total, s, !cfg.fix_lambda);
 
     // damped normal equations over the estimated columns (lm_optimizer.py:109-137)
-    float Hf[kMaxP][kMaxP], Gf[kMaxP];
-    unpack_system(acc, acc_pm(cfg.camera_model), Hf, Gf);
-    const Plan pl = make_plan(cfg);
-    float A[kMaxP][kMaxP], d[kMaxP + 1] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int i = 0; i < pl.n; ++i) {
-        d[i] = Gf[pl.cols[i]];
-        for (int j = 0; j < pl.n; ++j) A[i][j] = Hf[pl.cols[i]][pl.cols[j]];
+    float A[PM][PM], d[PM];
+    bool act[PM];
+    unpack_system<PM>(acc, A, d);
+    active_columns<PM>(cfg, act);
+#pragma unroll
+    for (int i = 0; i < PM; ++i) {
+#pragma unroll
+        for (int j = 0; j < PM; ++j)
+            if (!(act[i] && act[j])) A[i][j] = i == j ? 1.f : 0.f;
+        if (act[i]) A[i][i] += fmaxf(A[i][i] * s.lambda, 1e-6f); else d[i] = 0.f;
     }
-    for (int i = 0; i < pl.n; ++i) A[i][i] += fmaxf(A[i][i] * s.lambda, 1e-6f);
-    if (!chol_solve<kMaxP>(pl.n, A, d)) {
-        for (int i = 0; i <= kMaxP; ++i) d[i] = 0.f;   // zero step for THIS image (reference: whole batch)
+    if (!chol_solve<PM>(A, d)) {
+#pragma unroll
+        for (int i = 0; i < PM; ++i) d[i] = 0.f;     // zero step for THIS image (reference: whole batch)
         s.fails += 1.f;
     }
-    // update_estimate (lm_optimizer.py:518-549)
-    const float d0 = cfg.estimate_gravity ? d[0] : 0.f, d1 = cfg.estimate_gravity ? d[1] : 0.f;
-    const V3 g = grav_update({s.gx, s.gy, s.gz}, d0, d1, cfg.use_spherical_manifold != 0);
+    float dg0, dg1, df, dk1, dk2;
+    split_delta<PM>(cfg, d, dg0, dg1, df, dk1, dk2);
+    const V3 g = grav_update({s.gx, s.gy, s.gz}, dg0, dg1, cfg.use_spherical_manifold != 0);
     s.gx = g.x; s.gy = g.y; s.gz = g.z;
-    update_focal(s, cfg.estimate_focal ? d[pl.focal_dim] : 0.f, cfg.use_log_focal != 0);
-    if (cfg.camera_model != GCLM_PINHOLE && cfg.estimate_dist)
-        update_dist(s, cfg.camera_model, d[pl.dist_dim], d[pl.dist_dim + 1]);
+    update_focal(s, df, cfg.use_log_focal != 0);
+    if (cfg.camera_model != GCLM_PINHOLE && cfg.estimate_dist) update_dist(s, cfg.camera_model, dk1, dk2);
 
     c.state[(step + 1) & 1][b] = s;
     PBlock p;

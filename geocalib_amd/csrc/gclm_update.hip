@@ -28,6 +28,7 @@ __device__ inline bool coop_reduce_partials(const float* partials, int B, int nc
     }
     __syncthreads();
     if (b >= B || slot != 0) return false;
+#pragma unroll
     for (int i = 0; i < kNAccMax; ++i) acc[i] = i < nacc ? sacc[li][i] : 0.f;
     return true;
 }
@@ -94,12 +95,13 @@ __global__ void init_kernel(SolveCtx c, InitArgs ia) {
 }
 
 // Independent intrinsics: reduce the partial records, then one thread per image applies the LM step.
+template <int PM>
 __global__ __launch_bounds__(kImgPerBlock * kSlots) void update_kernel(SolveCtx c, int step) {
     if (c.cfg.early_stop && c.ctrl->stopped) return;          // block-uniform
     int b;
     float acc[kNAccMax];
     if (!coop_reduce_partials(c.partials, c.B, c.nchunks, acc_floats(c.cfg.camera_model), b, acc)) return;
-    update_image(c, step, b, acc);
+    update_image<PM>(c, step, b, acc);
 }
 
 // Batch-global early stop (lm_optimizer.py:619-625) decided on the device: after update `step`
@@ -122,26 +124,50 @@ __global__ void prep_final_kernel(SolveCtx c) {
     c.pb_final[b] = p;
 }
 
-// Inverse of an n x n matrix (n <= 5) by Gauss-Jordan with partial pivoting, in double.
-__device__ inline void invert(int n, const float (&A)[kMaxP][kMaxP], double (&inv)[kMaxP][kMaxP]) {
-    double M[kMaxP][2 * kMaxP];
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) { M[i][j] = A[i][j]; M[i][n + j] = i == j ? 1.0 : 0.0; }
-    for (int col = 0; col < n; ++col) {
-        int piv = col;
-        for (int r = col + 1; r < n; ++r) if (fabs(M[r][col]) > fabs(M[piv][col])) piv = r;
-        if (piv != col) for (int j = 0; j < 2 * n; ++j) { const double t = M[col][j]; M[col][j] = M[piv][j]; M[piv][j] = t; }
-        const double dv = M[col][col];
-        for (int j = 0; j < 2 * n; ++j) M[col][j] /= dv;
-        for (int r = 0; r < n; ++r) if (r != col) {
-            const double f = M[r][col];
-            for (int j = 0; j < 2 * n; ++j) M[r][j] -= f * M[col][j];
+// Inverse of an N x N SPD matrix through its Cholesky factor, in double, all sizes compile-time (registers).
+// torch.inverse (:484) uses a pivoted LU; on the SPD Hessians of this path both agree to rounding.
+template <int N>
+__device__ inline void spd_inverse(const float (&A)[N][N], double (&inv)[N][N]) {
+    double L[N][N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double sdiag = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) sdiag -= L[j][k] * L[j][k];
+        const double l = sqrt(sdiag);
+        L[j][j] = l;
+#pragma unroll
+        for (int i = j + 1; i < N; ++i) {
+            double t = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k];
+            L[i][j] = t / l;
         }
     }
-    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) inv[i][j] = M[i][n + j];
+#pragma unroll
+    for (int col = 0; col < N; ++col) {          // solve L L^T x = e_col
+        double x[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double t = i == col ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < i; ++k) t -= L[i][k] * x[k];
+            x[i] = t / L[i][i];
+        }
+#pragma unroll
+        for (int i = N - 1; i >= 0; --i) {
+            double t = x[i];
+#pragma unroll
+            for (int k = i + 1; k < N; ++k) t -= L[k][i] * x[k];
+            x[i] = t / L[i][i];
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) inv[i][col] = x[i];
+    }
 }
 
 // Final costs + estimate_uncertainty (lm_optimizer.py:632-642, 463-516) from the final sweep.
+template <int PM>
 __global__ __launch_bounds__(kImgPerBlock * kSlots) void finalize_kernel(SolveCtx c, float* cam, float* grav, float* info) {
     int b;
     float acc[kNAccMax];
@@ -162,20 +188,38 @@ __global__ __launch_bounds__(kImgPerBlock * kSlots) void finalize_kernel(SolveCt
     o[GCLM_INFO_FINAL_UP_COST] = cu;
     o[GCLM_INFO_FINAL_LAT_COST] = cl;
     o[GCLM_INFO_FINAL_COST] = total;
-    const Plan pl = make_plan(cfg);
-    o[GCLM_INFO_NPARAMS] = (float)pl.n;
+    bool act[PM];
+    active_columns<PM>(cfg, act);
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < PM; ++i) n += act[i] ? 1 : 0;
+    o[GCLM_INFO_NPARAMS] = (float)n;
     o[GCLM_INFO_LAMBDA] = s.lambda;
     o[GCLM_INFO_STEP_FAILURES] = s.fails;
     for (int i = GCLM_INFO_ROLL_UNC; i <= GCLM_INFO_VFOV_UNC; ++i) o[i] = 0.f;
     if (cfg.compute_uncertainty) {
-        float Hf[kMaxP][kMaxP], Gf[kMaxP], A[kMaxP][kMaxP];
-        unpack_system(acc, acc_pm(cfg.camera_model), Hf, Gf);
-        for (int i = 0; i < pl.n; ++i)
-            for (int j = 0; j < pl.n; ++j) A[i][j] = Hf[pl.cols[i]][pl.cols[j]];
-        double Cov[kMaxP][kMaxP];
-        invert(pl.n, A, Cov);                                 // torch.inverse(Hess), :484
-        for (int i = 0; i < pl.n; ++i)
-            for (int j = 0; j < pl.n; ++j) o[GCLM_INFO_COV + i * pl.n + j] = (float)Cov[i][j];
+        float A[PM][PM], Gf[PM];
+        unpack_system<PM>(acc, A, Gf);
+#pragma unroll
+        for (int i = 0; i < PM; ++i)
+#pragma unroll
+            for (int j = 0; j < PM; ++j)
+                if (!(act[i] && act[j])) A[i][j] = i == j ? 1.f : 0.f;
+        double Cov[PM][PM];
+        spd_inverse<PM>(A, Cov);                              // torch.inverse(Hess), :484
+        int ci = 0;                                           // compressed (free-parameter) indices
+#pragma unroll
+        for (int i = 0; i < PM; ++i) {
+            if (!act[i]) continue;
+            int cj = 0;
+#pragma unroll
+            for (int j = 0; j < PM; ++j) {
+                if (!act[j]) continue;
+                o[GCLM_INFO_COV + ci * n + cj] = (float)Cov[i][j];
+                ++cj;
+            }
+            ++ci;
+        }
         if (cfg.estimate_gravity) {
             const double c00 = Cov[0][0], c11 = Cov[1][1], c01 = 0.5 * (Cov[0][1] + Cov[1][0]);
             o[GCLM_INFO_ROLL_UNC] = (float)sqrt(c00);
@@ -184,7 +228,7 @@ __global__ __launch_bounds__(kImgPerBlock * kSlots) void finalize_kernel(SolveCt
             o[GCLM_INFO_GRAVITY_UNC] = (float)sqrt(tr + sqrt(df * df + c01 * c01));   // max eigvalsh, :495-496
         }
         if (cfg.estimate_focal) {
-            const double fu = Cov[pl.focal_dim][pl.focal_dim];
+            const double fu = Cov[2][2];
             const double fy = s.fy, hh = s.h;
             const double Jf = -4.0 * hh / (4.0 * fy * fy + hh * hh);                   // misc.py:285-287
             o[GCLM_INFO_FOCAL_UNC] = (float)(sqrt(fu) * 0.5);
@@ -247,7 +291,8 @@ __device__ inline void group_range(const SolveCtx& c, int g, int& f0, int& f1) {
 }
 
 // Damped 2x2 gravity block of a frame and its inverse; returns false if not positive definite.
-__device__ inline bool frame_block(const float (&Hf)[kMaxP][kMaxP], float lambda, float (&Dinv)[2][2]) {
+template <int PM>
+__device__ inline bool frame_block(const float (&Hf)[PM][PM], float lambda, float (&Dinv)[2][2]) {
     const float a = Hf[0][0] + fmaxf(Hf[0][0] * lambda, 1e-6f), b = Hf[0][1], d = Hf[1][1] + fmaxf(Hf[1][1] * lambda, 1e-6f);
     const float det = a * d - b * b;
     if (!(a > 0.f) || !(det > 0.f)) return false;
@@ -260,20 +305,21 @@ __device__ inline bool frame_block(const float (&Hf)[kMaxP][kMaxP], float lambda
 //   layout (GCLM_SHARED_PARTIAL_STRIDE = 32 floats): [0..9) sum E^T Dinv E (3x3 row-major), [9..12) sum E^T Dinv g,
 //   [12..21) sum H_ii, [21..24) sum g_i, [24] #frames; NaN in [0] marks a non-PD frame block.
 constexpr int kNI = 3, kGS = 0, kGR = 9, kGC = 12, kGc = 21, kGN = 24;
+template <int PM, int NI>
 __global__ void shared_group_kernel(SolveCtx c, int step, float* gp) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= c.n_groups) return;
     if (c.cfg.early_stop && c.ctrl->stopped) return;
-    const int ni = 1 + num_dist_params(c.cfg.camera_model), pm = acc_pm(c.cfg.camera_model);
+    constexpr int ni = NI;
     const int nacc = acc_floats(c.cfg.camera_model);
     int f0, f1;
     group_range(c, g, f0, f1);
     float S[kNI][kNI] = {}, r[kNI] = {}, C[kNI][kNI] = {}, cg[kNI] = {};
     bool ok = true;
     for (int f = f0; f < f1; ++f) {
-        float Hf[kMaxP][kMaxP], Gf[kMaxP], Dinv[2][2];
-        unpack_system(c.frame_sys + (size_t)f * nacc, pm, Hf, Gf);
-        ok = frame_block(Hf, c.state[step & 1][f].lambda, Dinv) && ok;
+        float Hf[PM][PM], Gf[PM], Dinv[2][2];
+        unpack_system<PM>(c.frame_sys + (size_t)f * nacc, Hf, Gf);
+        ok = frame_block<PM>(Hf, c.state[step & 1][f].lambda, Dinv) && ok;
         const float q0 = Dinv[0][0] * Gf[0] + Dinv[0][1] * Gf[1], q1 = Dinv[1][0] * Gf[0] + Dinv[1][1] * Gf[1];
         for (int i = 0; i < ni; ++i) {
             const float e0 = Hf[0][2 + i], e1 = Hf[1][2 + i];                         // E[:, i]
@@ -297,26 +343,31 @@ __global__ void shared_group_kernel(SolveCtx c, int step, float* gp) {
 
 // per frame: solve the (tiny) Schur system of its group from the REDUCED partials (redundantly per
 // frame: ni <= 3), back-substitute its own gravity block, update (lm_optimizer.py:597-606).
+template <int PM, int NI>
 __global__ void shared_apply_kernel(SolveCtx c, int step, const float* gp) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= c.B) return;
     if (c.cfg.early_stop && c.ctrl->stopped) return;
     const gclm_config& cfg = c.cfg;
-    const int ni = 1 + num_dist_params(cfg.camera_model), pm = acc_pm(cfg.camera_model);
+    constexpr int ni = NI;
     const int g = c.group_of_frame ? c.group_of_frame[b] : b / c.group_size;
     State s = c.state[step & 1][b];
     const float* o = gp + (size_t)g * GCLM_SHARED_PARTIAL_STRIDE;
-    float A[kNI][kNI], dI[kNI] = {}, dG[2] = {0.f, 0.f};
+    float A[NI][NI], dS[NI], dI[kNI] = {}, dG[2] = {0.f, 0.f};
     bool ok = o[0] == o[0];
-    for (int i = 0; i < ni; ++i) {
-        dI[i] = o[kGc + i] - o[kGR + i];
-        for (int j = 0; j < ni; ++j) A[i][j] = o[kGC + i * kNI + j] - o[kGS + i * kNI + j];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        dS[i] = o[kGc + i] - o[kGR + i];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) A[i][j] = o[kGC + i * kNI + j] - o[kGS + i * kNI + j];
         A[i][i] += fmaxf(o[kGC + i * kNI + i] * s.lambda, 1e-6f);      // damping on sum H_ii (:123-126)
     }
-    ok = ok && chol_solve<kNI>(ni, A, dI);
-    float Hf[kMaxP][kMaxP], Gf[kMaxP], Dinv[2][2];
-    unpack_system(c.frame_sys + (size_t)b * acc_floats(cfg.camera_model), pm, Hf, Gf);
-    ok = ok && frame_block(Hf, s.lambda, Dinv);
+    ok = chol_solve<NI>(A, dS) && ok;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) dI[i] = dS[i];
+    float Hf[PM][PM], Gf[PM], Dinv[2][2];
+    unpack_system<PM>(c.frame_sys + (size_t)b * acc_floats(cfg.camera_model), Hf, Gf);
+    ok = frame_block<PM>(Hf, s.lambda, Dinv) && ok;
     if (ok) {
         float r0 = Gf[0], r1 = Gf[1];
         for (int i = 0; i < ni; ++i) { r0 -= Hf[0][2 + i] * dI[i]; r1 -= Hf[1][2 + i] * dI[i]; }
@@ -351,6 +402,7 @@ __global__ void pblock_from_params_kernel(SolveCtx c, const float* cam, const fl
     out[b] = p;
 }
 
+template <int PM>
 __global__ __launch_bounds__(kImgPerBlock * kSlots) void system_out_kernel(SolveCtx c, float* cost, float* grad, float* hess) {
     int b;
     float acc[kNAccMax];
@@ -358,11 +410,14 @@ __global__ __launch_bounds__(kImgPerBlock * kSlots) void system_out_kernel(Solve
     const float invN = 1.0f / (float)((size_t)c.H * c.W);
     cost[b * 2] = acc[A_CU] * invN;
     cost[b * 2 + 1] = acc[A_CL] * invN;
-    float Hf[kMaxP][kMaxP], Gf[kMaxP];
-    unpack_system(acc, acc_pm(c.cfg.camera_model), Hf, Gf);
+    float Hf[PM][PM], Gf[PM];
+    unpack_system<PM>(acc, Hf, Gf);
+#pragma unroll
     for (int i = 0; i < GCLM_MAX_PARAMS; ++i) {
-        grad[b * GCLM_MAX_PARAMS + i] = Gf[i];
-        for (int j = 0; j < GCLM_MAX_PARAMS; ++j) hess[(b * GCLM_MAX_PARAMS + i) * GCLM_MAX_PARAMS + j] = Hf[i][j];
+        grad[b * GCLM_MAX_PARAMS + i] = i < PM ? Gf[i < PM ? i : 0] : 0.f;
+#pragma unroll
+        for (int j = 0; j < GCLM_MAX_PARAMS; ++j)
+            hess[(b * GCLM_MAX_PARAMS + i) * GCLM_MAX_PARAMS + j] = (i < PM && j < PM) ? Hf[i < PM ? i : 0][j < PM ? j : 0] : 0.f;
     }
 }
 
@@ -546,7 +601,8 @@ hipError_t launch_init(const SolveCtx& c, const InitArgs& ia, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_update(const SolveCtx& c, int step, hipStream_t s) {
-    GCLM_LR(update_kernel, c.B, s, c, step);
+    if (acc_pm(c.cfg.camera_model) == 5) GCLM_LR(update_kernel<5>, c.B, s, c, step);
+    else GCLM_LR(update_kernel<4>, c.B, s, c, step);
     return hipGetLastError();
 }
 hipError_t launch_decide(const SolveCtx& c, int step, hipStream_t s) {
@@ -558,21 +614,31 @@ hipError_t launch_prep_final(const SolveCtx& c, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_finalize(const SolveCtx& c, float* d_cam, float* d_grav, float* d_info, hipStream_t s) {
-    GCLM_LR(finalize_kernel, c.B, s, c, d_cam, d_grav, d_info);
+    if (acc_pm(c.cfg.camera_model) == 5) GCLM_LR(finalize_kernel<5>, c.B, s, c, d_cam, d_grav, d_info);
+    else GCLM_LR(finalize_kernel<4>, c.B, s, c, d_cam, d_grav, d_info);
     GCLM_L(stop_at_kernel, c.B, s, c, d_info);
     return hipGetLastError();
 }
 hipError_t launch_shared_reduce(const SolveCtx& c, int step, float* d_group_partials, hipStream_t s) {
     if (c.B > 0) GCLM_LR(shared_frame_kernel, c.B, s, c, step);
-    GCLM_L(shared_group_kernel, c.n_groups, s, c, step, d_group_partials);
+    switch (c.cfg.camera_model) {
+        case GCLM_PINHOLE: GCLM_L((shared_group_kernel<4, 1>), c.n_groups, s, c, step, d_group_partials); break;
+        case GCLM_RADIAL: GCLM_L((shared_group_kernel<5, 3>), c.n_groups, s, c, step, d_group_partials); break;
+        default: GCLM_L((shared_group_kernel<4, 2>), c.n_groups, s, c, step, d_group_partials); break;
+    }
     return hipGetLastError();
 }
 hipError_t launch_shared_apply(const SolveCtx& c, int step, const float* d_group_partials, hipStream_t s) {
-    GCLM_L(shared_apply_kernel, c.B, s, c, step, d_group_partials);
+    switch (c.cfg.camera_model) {
+        case GCLM_PINHOLE: GCLM_L((shared_apply_kernel<4, 1>), c.B, s, c, step, d_group_partials); break;
+        case GCLM_RADIAL: GCLM_L((shared_apply_kernel<5, 3>), c.B, s, c, step, d_group_partials); break;
+        default: GCLM_L((shared_apply_kernel<4, 2>), c.B, s, c, step, d_group_partials); break;
+    }
     return hipGetLastError();
 }
 hipError_t launch_system_out(const SolveCtx& c, float* d_cost, float* d_grad, float* d_hess, hipStream_t s) {
-    GCLM_LR(system_out_kernel, c.B, s, c, d_cost, d_grad, d_hess);
+    if (acc_pm(c.cfg.camera_model) == 5) GCLM_LR(system_out_kernel<5>, c.B, s, c, d_cost, d_grad, d_hess);
+    else GCLM_LR(system_out_kernel<4>, c.B, s, c, d_cost, d_grad, d_hess);
     return hipGetLastError();
 }
 hipError_t launch_pblock_from_params(const SolveCtx& c, const float* d_cam, const float* d_grav, int as_rpf,
