@@ -559,3 +559,26 @@ def test_c_abi_from_plain_c(dev, tmp_path):
         assert np.allclose(got[:, 1], gtc[:, 3].cpu().numpy(), rtol=2e-6)
         assert np.allclose(got[:, 2], out["camera"][:, 6], atol=2e-5)
         assert np.allclose(got[:, 3:6], out["gravity"], atol=2e-5)
+
+
+@pytest.mark.parametrize("extra", [[], ["--shared-group", "16"]])
+def test_bench_multi_rank_path_on_one_gpu(dev, extra):
+    """bench.py's N>1 code path (image sharding + ONE gather; shared-intrinsics frame split + ONE all-reduce per
+    step) with two real processes that share this GPU and talk over gloo: the JSON line must describe the
+    whole job and the solve must still recover the ground truth (bench.py asserts that itself)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    port = 29500 + (os.getpid() % 400)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+           "--batch", "64", "--steps", "2", "--warmup", "1", "--cpu-sample", "0"] + extra
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 128 and out["scaling"] == "weak"
+    assert out["value"] > 0 and out["unit"] == "images/sec" and out["steps"] == 2
+    assert out["check"]["median_focal_rel_err_vs_gt"] < 5e-3
+    assert "cpu_baseline" not in out and out["roofline"]["launches_timed"] == 2 * 21
