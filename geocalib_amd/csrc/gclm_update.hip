@@ -11,25 +11,46 @@ namespace {
 using namespace dev;
 
 // Sum the workgroup partials of the images of this block in a fixed order (double accumulate).
-// Block-cooperative: 256 threads = 8 images x 32 slots (the first `nacc` = 16 or 24 are accumulator slots);
-// thread (image, slot) walks the image's chunk records (coalesced over the slots), the per-image leader
-// (slot 0) then owns the sums.  Returns true for leaders.  Must be called by every thread of the block.
-constexpr int kImgPerBlock = 8, kSlots = 32;
+// Block-cooperative, 256 threads = 8 groups x 32 slots (the first `nacc` = 16 or 24 are accumulator slots).
+// Few chunks per image (large batches): a group is an image, thread (image, slot) walks that image's chunk
+// records (coalesced over the slots).  Many chunks per image (small batches of large images, where one serial
+// walk is a latency chain of hundreds of dependent loads): the block takes ONE image and the 8 groups are
+// stripes of its chunks, combined in stripe order.  The per-image leader then owns the sums.  Returns true for
+// leaders.  Must be called by every thread of the block; launch with reduce_blocks(B, nchunks) blocks.
+constexpr int kGroups = 8, kSlots = 32, kStripeMinChunks = 33;
+__host__ __device__ inline int reduce_images_per_block(int nchunks) { return nchunks >= kStripeMinChunks ? 1 : kGroups; }
+inline int reduce_blocks(int B, int nchunks) {
+    const int ipb = reduce_images_per_block(nchunks);
+    return (B + ipb - 1) / ipb;
+}
 __device__ inline bool coop_reduce_partials(const float* partials, int B, int nchunks, int nacc, int& b,
                                             float (&acc)[kNAccMax]) {
-    __shared__ float sacc[kImgPerBlock][kSlots + 1];
-    const int li = threadIdx.x / kSlots, slot = threadIdx.x % kSlots;
-    b = blockIdx.x * kImgPerBlock + li;
+    __shared__ double sacc[kGroups][kSlots + 1];
+    const int grp = threadIdx.x / kSlots, slot = threadIdx.x % kSlots;
+    const bool striped = reduce_images_per_block(nchunks) == 1;
+    b = striped ? (int)blockIdx.x : (int)blockIdx.x * kGroups + grp;
+    const int first = striped ? grp : 0, stride = striped ? kGroups : 1;
     if (b < B && slot < nacc) {
         double d = 0.0;
         const float* p = partials + (size_t)b * nchunks * nacc + slot;
-        for (int c = 0; c < nchunks; ++c) d += p[(size_t)c * nacc];
-        sacc[li][slot] = (float)d;
+#pragma unroll 4
+        for (int c = first; c < nchunks; c += stride) d += p[(size_t)c * nacc];
+        sacc[grp][slot] = d;
     }
     __syncthreads();
-    if (b >= B || slot != 0) return false;
+    if (b >= B || slot != 0 || (striped && grp != 0)) return false;
+    if (striped) {
 #pragma unroll
-    for (int i = 0; i < kNAccMax; ++i) acc[i] = i < nacc ? sacc[li][i] : 0.f;
+        for (int i = 0; i < kNAccMax; ++i) {
+            double d = 0.0;
+            if (i < nacc)
+                for (int g = 0; g < kGroups; ++g) d += sacc[g][i];
+            acc[i] = (float)d;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kNAccMax; ++i) acc[i] = i < nacc ? (float)sacc[grp][i] : 0.f;
+    }
     return true;
 }
 
@@ -96,7 +117,7 @@ __global__ void init_kernel(SolveCtx c, InitArgs ia) {
 
 // Independent intrinsics: reduce the partial records, then one thread per image applies the LM step.
 template <int PM>
-__global__ __launch_bounds__(kImgPerBlock * kSlots) void update_kernel(SolveCtx c, int step) {
+__global__ __launch_bounds__(kGroups * kSlots) void update_kernel(SolveCtx c, int step) {
     if (c.cfg.early_stop && c.ctrl->stopped) return;          // block-uniform
     int b;
     float acc[kNAccMax];
@@ -168,7 +189,7 @@ __device__ inline void spd_inverse(const float (&A)[N][N], double (&inv)[N][N]) 
 
 // Final costs + estimate_uncertainty (lm_optimizer.py:632-642, 463-516) from the final sweep.
 template <int PM>
-__global__ __launch_bounds__(kImgPerBlock * kSlots) void finalize_kernel(SolveCtx c, float* cam, float* grav, float* info) {
+__global__ __launch_bounds__(kGroups * kSlots) void finalize_kernel(SolveCtx c, float* cam, float* grav, float* info) {
     int b;
     float acc[kNAccMax];
     if (!coop_reduce_partials(c.partials, c.B, c.nchunks, acc_floats(c.cfg.camera_model), b, acc)) return;
@@ -260,7 +281,7 @@ __global__ void stop_at_kernel(SolveCtx c, float* info) {
 // be all-reduced across devices when a group's frames are sharded (BASELINE config 5).
 
 // per frame: reduce partials -> frame_sys, costs / allclose bookkeeping
-__global__ __launch_bounds__(kImgPerBlock * kSlots) void shared_frame_kernel(SolveCtx c, int step) {
+__global__ __launch_bounds__(kGroups * kSlots) void shared_frame_kernel(SolveCtx c, int step) {
     if (c.cfg.early_stop && c.ctrl->stopped) return;
     int b;
     float acc[kNAccMax];
@@ -403,7 +424,7 @@ __global__ void pblock_from_params_kernel(SolveCtx c, const float* cam, const fl
 }
 
 template <int PM>
-__global__ __launch_bounds__(kImgPerBlock * kSlots) void system_out_kernel(SolveCtx c, float* cost, float* grad, float* hess) {
+__global__ __launch_bounds__(kGroups * kSlots) void system_out_kernel(SolveCtx c, float* cost, float* grad, float* hess) {
     int b;
     float acc[kNAccMax];
     if (!coop_reduce_partials(c.partials, c.B, c.nchunks, acc_floats(c.cfg.camera_model), b, acc)) return;
@@ -592,9 +613,9 @@ inline dim3 grid1(int n) { return dim3((n + 127) / 128); }
 }  // namespace
 
 #define GCLM_L(kernel, n, s, ...) hipLaunchKernelGGL(kernel, grid1(n), dim3(128), 0, s, __VA_ARGS__)
-// cooperative-reduce kernels: 8 images per 256-thread block
+// cooperative-reduce kernels: 256-thread blocks of 8 images (or 1 striped image, see coop_reduce_partials)
 #define GCLM_LR(kernel, n, s, ...) \
-    hipLaunchKernelGGL(kernel, dim3(((n) + kImgPerBlock - 1) / kImgPerBlock), dim3(kImgPerBlock * kSlots), 0, s, __VA_ARGS__)
+    hipLaunchKernelGGL(kernel, dim3(reduce_blocks((n), c.nchunks)), dim3(kGroups * kSlots), 0, s, __VA_ARGS__)
 
 hipError_t launch_init(const SolveCtx& c, const InitArgs& ia, hipStream_t s) {
     GCLM_L(init_kernel, c.B, s, c, ia);
