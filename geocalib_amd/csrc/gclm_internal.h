@@ -51,12 +51,20 @@ struct __attribute__((aligned(16))) State {
 static_assert(sizeof(State) == kStateFloats * 4, "State layout");
 
 // Device-side control block: batch-global early stop without host synchronisation.
+// Batch-global early stop (lm_optimizer.py:619-625) without a host sync or a decision kernel: update `s`
+// counts the images whose cost still moved into notclose[s]; the stop fires after the first update s >= 1
+// that leaves notclose[s] == 0.  Every later launch of the loop is skipped, so its own counter stays 0 too,
+// hence "the stop fired before LM step k"  <=>  k >= 2 && notclose[k-1] == 0.
 struct Ctrl {
-    int stopped;                           // set once every image's cost is "close" (early_stop)
+    int stopped;                           // set by prep_final once the early stop has fired
     int final_sel;                         // state buffer (0/1) that holds the final estimate
     int pad[2];
     int notclose[GCLM_MAX_STEPS + 4];      // per step: number of images whose cost still moved
 };
+
+__host__ __device__ inline bool stop_fired_before(const Ctrl* ctrl, int step) {
+    return step >= 2 && ctrl->notclose[step - 1] == 0;
+}
 
 struct SweepArgs {
     const float* up;        // (B,2,H,W) or nullptr
@@ -70,7 +78,7 @@ struct SweepArgs {
     int nchunks;            // blocks per image
     int units_per_block;    // float4 groups (or pixels in the scalar path) per block
     int vec;                // 4: float4 path, 1: scalar path
-    int skip_if_stopped;    // loop sweeps return immediately once ctrl->stopped is set
+    int stop_step;          // >= 2: LM step of this loop sweep, skipped once the early stop has fired (else 0)
     float up_scale, lat_scale;   // Huber scales a (lm_optimizer.py:158-159)
 };
 
@@ -108,7 +116,6 @@ struct InitArgs {              // initial estimate: explicit (cam, grav) or triv
 };
 hipError_t launch_init(const SolveCtx& c, const InitArgs& ia, hipStream_t s);
 hipError_t launch_update(const SolveCtx& c, int step, hipStream_t s);
-hipError_t launch_decide(const SolveCtx& c, int step, hipStream_t s);
 hipError_t launch_prep_final(const SolveCtx& c, hipStream_t s);
 hipError_t launch_finalize(const SolveCtx& c, float* d_cam, float* d_grav, float* d_info, hipStream_t s);
 hipError_t launch_shared_reduce(const SolveCtx& c, int step, float* d_group_partials, hipStream_t s);

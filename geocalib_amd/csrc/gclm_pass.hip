@@ -502,7 +502,7 @@ template <int MODEL, bool HAS_UP, bool HAS_UPC, bool HAS_LATC, int VEC>
 // reach 96 / 128 on their own
 __global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL >= GCLM_RADIAL) ? 3 : GCLM_MIN_WAVES) void sweep_kernel(
     const SweepArgs a) {
-    if (a.skip_if_stopped && a.ctrl->stopped) return;   // batch-global early stop, no host sync
+    if (stop_fired_before(a.ctrl, a.stop_step)) return;   // batch-global early stop, no host sync
     constexpr int NACC = Layout<MODEL>::NACC;
     const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
     const PBlock P = a.pb[b];                            // workgroup-uniform -> scalar loads

@@ -118,28 +118,25 @@ __global__ void init_kernel(SolveCtx c, InitArgs ia) {
 // Independent intrinsics: reduce the partial records, then one thread per image applies the LM step.
 template <int PM>
 __global__ __launch_bounds__(kGroups * kSlots) void update_kernel(SolveCtx c, int step) {
-    if (c.cfg.early_stop && c.ctrl->stopped) return;          // block-uniform
+    if (c.cfg.early_stop && stop_fired_before(c.ctrl, step)) return;          // block-uniform
     int b;
     float acc[kNAccMax];
     if (!coop_reduce_partials(c.partials, c.B, c.nchunks, acc_floats(c.cfg.camera_model), b, acc)) return;
     update_image<PM>(c, step, b, acc);
 }
 
-// Batch-global early stop (lm_optimizer.py:619-625) decided on the device: after update `step`
-// every image has compared cost(theta_step) with the previous one.
-__global__ void decide_kernel(SolveCtx c, int step) {
-    if (c.ctrl->stopped || step < 1) return;
-    if (c.ctrl->notclose[step] == 0) {
-        c.ctrl->stopped = 1;
-        c.ctrl->final_sel = step & 1;      // theta_step: the tentative theta_{step+1} is discarded
-    }
-}
-
 // Parameter block of the final sweep: (roll, pitch, focal) parametrisation (lm_optimizer.py:481-483).
 __global__ void prep_final_kernel(SolveCtx c) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    // which state buffer is final: theta_s if the early stop fired after update s (the tentative theta_{s+1}
+    // is discarded, :619-625), else theta_{num_steps}
+    int sel = c.cfg.num_steps & 1, stopped = 0;
+    if (c.cfg.early_stop)
+        for (int j = 1; j < c.cfg.num_steps; ++j)
+            if (c.ctrl->notclose[j] == 0) { sel = j & 1; stopped = 1; break; }
+    if (b == 0) { c.ctrl->stopped = stopped; c.ctrl->final_sel = sel; }    // for finalize_kernel
     if (b >= c.B) return;
-    const State s = c.state[c.ctrl->final_sel][b];
+    const State s = c.state[sel][b];
     PBlock p;
     build_pblock(s, false, false, p);
     c.pb_final[b] = p;
@@ -282,7 +279,7 @@ __global__ void stop_at_kernel(SolveCtx c, float* info) {
 
 // per frame: reduce partials -> frame_sys, costs / allclose bookkeeping
 __global__ __launch_bounds__(kGroups * kSlots) void shared_frame_kernel(SolveCtx c, int step) {
-    if (c.cfg.early_stop && c.ctrl->stopped) return;
+    if (c.cfg.early_stop && stop_fired_before(c.ctrl, step)) return;
     int b;
     float acc[kNAccMax];
     if (!coop_reduce_partials(c.partials, c.B, c.nchunks, acc_floats(c.cfg.camera_model), b, acc)) return;
@@ -330,7 +327,7 @@ template <int PM, int NI>
 __global__ void shared_group_kernel(SolveCtx c, int step, float* gp) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= c.n_groups) return;
-    if (c.cfg.early_stop && c.ctrl->stopped) return;
+    if (c.cfg.early_stop && stop_fired_before(c.ctrl, step)) return;
     constexpr int ni = NI;
     const int nacc = acc_floats(c.cfg.camera_model);
     int f0, f1;
@@ -368,7 +365,7 @@ template <int PM, int NI>
 __global__ void shared_apply_kernel(SolveCtx c, int step, const float* gp) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= c.B) return;
-    if (c.cfg.early_stop && c.ctrl->stopped) return;
+    if (c.cfg.early_stop && stop_fired_before(c.ctrl, step)) return;
     const gclm_config& cfg = c.cfg;
     constexpr int ni = NI;
     const int g = c.group_of_frame ? c.group_of_frame[b] : b / c.group_size;
@@ -624,10 +621,6 @@ hipError_t launch_init(const SolveCtx& c, const InitArgs& ia, hipStream_t s) {
 hipError_t launch_update(const SolveCtx& c, int step, hipStream_t s) {
     if (acc_pm(c.cfg.camera_model) == 5) GCLM_LR(update_kernel<5>, c.B, s, c, step);
     else GCLM_LR(update_kernel<4>, c.B, s, c, step);
-    return hipGetLastError();
-}
-hipError_t launch_decide(const SolveCtx& c, int step, hipStream_t s) {
-    hipLaunchKernelGGL(decide_kernel, dim3(1), dim3(1), 0, s, c, step);
     return hipGetLastError();
 }
 hipError_t launch_prep_final(const SolveCtx& c, hipStream_t s) {
