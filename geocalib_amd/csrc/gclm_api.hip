@@ -109,12 +109,13 @@ int ensure_workspace(gclm_handle* h, int B, int nchunks, int G) {
 }
 
 SweepArgs sweep_args(const gclm_handle* h, const float* up, const float* lat, const float* upc, const float* latc,
-                     const PBlock* pb, const Geometry& g, int stop_step) {
+                     const PBlock* pb, const Geometry& g, bool loop_params, int stop_step) {
     SweepArgs a{};
     a.up = up; a.lat = lat; a.upc = up ? upc : nullptr; a.latc = latc;
     a.pb = pb; a.ctrl = h->ctx.ctrl; a.partials = h->ctx.partials;
     a.B = h->ctx.B; a.H = h->ctx.H; a.W = h->ctx.W;
     a.nchunks = g.nchunks; a.units_per_block = g.units_per_block; a.vec = g.vec;
+    a.log_focal = loop_params && h->cfg.use_log_focal;   // else the (roll, pitch, focal) block of the final sweep
     a.stop_step = stop_step;
     a.up_scale = h->cfg.up_loss_fn_scale; a.lat_scale = h->cfg.lat_loss_fn_scale;
     return a;
@@ -280,7 +281,7 @@ static int run_solve(gclm_handle* h, const float* d_up, const float* d_lat, cons
     GCLM_HIP(h, launch_init(c, ia, s));
     const bool es = h->cfg.early_stop != 0;
     for (int step = 0; step < h->cfg.num_steps; ++step) {
-        const SweepArgs a = sweep_args(h, d_up, d_lat, d_up_conf, d_lat_conf, c.pb[step & 1], geo, es ? step : 0);
+        const SweepArgs a = sweep_args(h, d_up, d_lat, d_up_conf, d_lat_conf, c.pb[step & 1], geo, true, es ? step : 0);
         if (int rc = timed_sweep(h, a, s)) return rc;
         if (!h->cfg.shared_intrinsics) {
             GCLM_HIP(h, launch_update(c, step, s));
@@ -290,7 +291,7 @@ static int run_solve(gclm_handle* h, const float* d_up, const float* d_lat, cons
         }
     }
     GCLM_HIP(h, launch_prep_final(c, s));
-    const SweepArgs a = sweep_args(h, d_up, d_lat, d_up_conf, d_lat_conf, c.pb_final, geo, 0);
+    const SweepArgs a = sweep_args(h, d_up, d_lat, d_up_conf, d_lat_conf, c.pb_final, geo, false, 0);
     if (int rc = timed_sweep(h, a, s)) return rc;
     GCLM_HIP(h, launch_finalize(c, d_cam_out, d_grav_out, d_info_out, s));
     return 0;
@@ -346,7 +347,7 @@ int gclm_system(gclm_handle* h, const float* d_up, const float* d_lat, const flo
     if (int rc = ensure_workspace(h, B, geo.nchunks, 0)) return rc;
     h->sh.active = false;
     GCLM_HIP(h, launch_pblock_from_params(c, d_cam, d_grav, as_rpf, c.pb_final, s));
-    const SweepArgs a = sweep_args(h, d_up, d_lat, d_up_conf, d_lat_conf, c.pb_final, geo, 0);
+    const SweepArgs a = sweep_args(h, d_up, d_lat, d_up_conf, d_lat_conf, c.pb_final, geo, !as_rpf, 0);
     GCLM_HIP(h, launch_sweep(h->cfg.camera_model, a, s));
     GCLM_HIP(h, launch_system_out(c, d_cost, d_grad, d_hess, s));
     return 0;
@@ -388,7 +389,7 @@ int gclm_shared_reduce(gclm_handle* h, int step, float* d_partials, void* stream
     GCLM_HIP(h, hipSetDevice(h->device));
     SolveCtx& c = h->ctx;
     if (c.B > 0) {
-        const SweepArgs a = sweep_args(h, h->sh.up, h->sh.lat, h->sh.upc, h->sh.latc, c.pb[step & 1], h->sh.geo, 0);
+        const SweepArgs a = sweep_args(h, h->sh.up, h->sh.lat, h->sh.upc, h->sh.latc, c.pb[step & 1], h->sh.geo, true, 0);
         if (int rc = timed_sweep(h, a, s)) return rc;
     }
     GCLM_HIP(h, launch_shared_reduce(c, step, d_partials, s));
@@ -416,7 +417,7 @@ int gclm_shared_finish(gclm_handle* h, float* d_info_out, void* stream) {
     if (c.B == 0) return 0;
     GCLM_HIP(h, hipMemsetAsync(d_info_out, 0, sizeof(float) * GCLM_INFO_STRIDE * (size_t)c.B, s));
     GCLM_HIP(h, launch_prep_final(c, s));
-    const SweepArgs a = sweep_args(h, h->sh.up, h->sh.lat, h->sh.upc, h->sh.latc, c.pb_final, h->sh.geo, 0);
+    const SweepArgs a = sweep_args(h, h->sh.up, h->sh.lat, h->sh.upc, h->sh.latc, c.pb_final, h->sh.geo, false, 0);
     if (int rc = timed_sweep(h, a, s)) return rc;
     GCLM_HIP(h, launch_finalize(c, h->sh.cam_io, h->sh.grav_io, d_info_out, s));
     return 0;

@@ -78,6 +78,7 @@ struct SweepArgs {
     int nchunks;            // blocks per image
     int units_per_block;    // float4 groups (or pixels in the scalar path) per block
     int vec;                // 4: float4 path, 1: scalar path
+    int log_focal;          // the parameter block was built for the log-focal parametrisation (wfx = wfy = 1)
     int stop_step;          // >= 2: LM step of this loop sweep, skipped once the early stop has fired (else 0)
     float up_scale, lat_scale;   // Huber scales a (lm_optimizer.py:158-159)
 };

@@ -45,6 +45,9 @@
 #ifndef GCLM_MIN_WAVES
 #define GCLM_MIN_WAVES 1
 #endif
+#ifndef GCLM_LOGF
+#define GCLM_LOGF 1            // A/B switch: 0 = always the general focal-column code
+#endif
 #ifndef GCLM_NT_LOADS
 #define GCLM_NT_LOADS 1
 #endif
@@ -102,23 +105,27 @@ __device__ __forceinline__ F sin_halfpi(F x) {
     return vfma(x * t, p, x);
 }
 
-// Scaled Huber on the squared residual x2 (lm_optimizer.py:61-87), in units of a^2: returns
-// cost / a^2 (the a^2 factor is applied once per workgroup) and sets the weight.  Branch-free form:
-//   weight = min(1, 1/sqrt(y + 1e-8))           (= 1 for y <= 1, = 1/sqrt(y) beyond)
-//   cost   = 2 y weight - min(y, 1)             (= y for y <= 1, = 2 sqrt(y) - 1 beyond)
-// identical to the reference's where(y <= 1, ...) selects up to 2e-8 relative (the 1e-8 inside the sqrt).
-// The reference's max(eps, 1/sqrt(y)) only matters for y > 7e13; residuals here are bounded
+// Scaled Huber on the squared residual x2 (lm_optimizer.py:61-87), in units of a^2 (the a^2 factor of the cost
+// is applied once per workgroup): adds confidence * cost / a^2 to `cost_acc` and returns confidence * weight.
+// Branch-free form, y = x2 / a^2:
+//   weight = min(1, 1/sqrt(y))                  (= 1 for y <= 1, = 1/sqrt(y) beyond; y = 0: rsq = +inf -> 1)
+//   cost   = y weight (2 - weight)              (= y for y <= 1, = 2 sqrt(y) - 1 beyond)
+// The reference's where(y <= 1, ...) selects evaluate sqrt(y + 1e-8): a relative difference below 5e-9 for the
+// y > 1 they apply to.  Its max(eps, 1/sqrt(y)) only matters for y > 7e13; residuals here are bounded
 // (|r_up| <= 2, |r_lat| <= 2 => y <= 4/a^2), so it is the identity and is dropped.
 template <typename F>
-__device__ __forceinline__ F huber(F x2, float inv_a2, F& weight) {
+__device__ __forceinline__ F huber_accumulate(F x2, float inv_a2, F conf, F& cost_acc) {
     const F y = x2 * inv_a2;
-    const F isx = vrsq(y + 1e-8f);
 #if GCLM_HUBER_SELECT      // A/B switch: the reference's literal select form
-    weight = vsel_le1(y, vsplat(y, 1.0f), isx);
-    return vsel_le1(y, y, vfma(2.0f * (y + 1e-8f), isx, vsplat(y, -1.0f)));
+    const F isx = vrsq(y + 1e-8f);
+    const F weight = vsel_le1(y, vsplat(y, 1.0f), isx);
+    cost_acc = vfma(vsel_le1(y, y, vfma(2.0f * (y + 1e-8f), isx, vsplat(y, -1.0f))), conf, cost_acc);
+    return weight * conf;
 #else
-    weight = vmin1(isx);
-    return vfma(2.0f * y, weight, -vmin1(y));
+    const F weight = vmin1(vrsq(y));
+    const F wc = weight * conf;
+    cost_acc = vfma(y * wc, 2.0f - weight, cost_acc);
+    return wc;
 #endif
 }
 
@@ -225,16 +232,25 @@ __device__ __forceinline__ void accumulate(F (&acc)[Layout<MODEL>::NACC], const 
 // Hand-scheduled form of the same math for the two BASELINE models (pinhole, simple_radial): identical
 // operations to pixel_accumulate<> below with the model terms substituted, written out so that the
 // compiler reaches 96 / 128 VGPRs (5 / 4 waves per SIMD) without spills or dependency stalls.
-template <int MODEL, bool HAS_UP, typename F>
+//
+// LOGF: the focal parameter is log f (every loop sweep of the default conf), so d(uv)/dtheta_f = w = -(u,v)
+// exactly and every "x . w" product is minus the matching "x . uv" product that is computed anyway:
+// n.w = -n.uv, m.w = -m.uv, uv.w = -r2, p.w = -t, h.w = -h.uv, and the focal column collapses to
+//   up:  s2 = c (m.uv) - 2 k1 s3          lat:  l2 = -e (h.uv) - 2 k1 l3
+template <int MODEL, bool HAS_UP, bool LOGF, typename F>
 __device__ __forceinline__ void pixel_accumulate_fast(const PBlock& P, const HuberK& hk, F xf, float yf, F dux, F duy,
                                                  F dlat, F cu, F cl, F (&acc)[kNAcc]) {
     constexpr bool DIST = MODEL != GCLM_PINHOLE;
     const F u = (xf - P.cx) * P.ifx;
     const float v = (yf - P.cy) * P.ify;                 // one image row per tile: v is lane-scalar
     const F r2 = vfma(u, u, vsplat(u, v * v));
-    const F wx = u * (-P.wfx);                           // d(uv)/d(focal parameter) = (wx, wy)
-    const float wy = -v * P.wfy;
-    const F uvw = vfma(u, wx, vsplat(u, v * wy));
+    [[maybe_unused]] F wx = vsplat(u, 0.f), uvw = vsplat(u, 0.f);
+    [[maybe_unused]] float wy = 0.f;
+    if constexpr (!LOGF) {
+        wx = u * (-P.wfx);                               // d(uv)/d(focal parameter) = (wx, wy)
+        wy = -v * P.wfy;
+        uvw = vfma(u, wx, vsplat(u, v * wy));
+    }
     const float k1x2 = 2.0f * P.k1;
 
     if constexpr (HAS_UP) {
@@ -253,33 +269,36 @@ __device__ __forceinline__ void pixel_accumulate_fast(const PBlock& P, const Hub
         const F ux = qx * rn, uy = qy * rn;              // predicted up vector
         const F rx = dux - ux, ry = duy - uy;            // residual (lm_optimizer.py:266)
         const F x2 = vfma(rx, rx, ry * ry);
-        F wgt;
-        const F cost = huber(x2, hk.inv_a2u, wgt);
-        wgt = wgt * cu;
-        acc[A_CU] = vfma(cost, cu, acc[A_CU]);
+        const F wgt = huber_accumulate(x2, hk.inv_a2u, cu, acc[A_CU]);
         // rank-one Jacobian: s_k = (M nq) . dp/dtheta_k, nq = n/|q|, n = (-uy, ux);  rho = n . r
         const F nx = -uy * rn, ny = ux * rn;
         const F nuv = vfma(nx, u, ny * v);
-        const F nw = vfma(nx, wx, ny * wy);
+        [[maybe_unused]] F nw = vsplat(u, 0.f);
+        if constexpr (!LOGF) nw = vfma(nx, wx, ny * wy);
         F mx = nx, my = ny, muv = nuv, mw = nw;
         if constexpr (DIST) {
             const F c2 = nuv * k1x2;
             mx = vfma(d, nx, c2 * u);
             my = vfma(d, ny, c2 * v);
             muv = vfma(mx, u, my * v);
-            mw = vfma(mx, wx, my * wy);
+            if constexpr (!LOGF) mw = vfma(mx, wx, my * wy);
         }
         // dp/ddelta_k = (T0k - u T2k, T1k - v T2k)  =>  s_k = m.T[0:2,k] - (m.uv) T2k
         const F s0 = vfma(mx, vsplat(u, P.T00), vfma(my, vsplat(u, P.T10), muv * (-P.T20)));
         const F s1 = vfma(mx, vsplat(u, P.T01), vfma(my, vsplat(u, P.T11), muv * (-P.T21)));
-        F s2 = mw * (-P.gc);                             // dp/df = -c w
+        F s2 = LOGF ? muv * P.gc : mw * (-P.gc);         // dp/df = -c w
         [[maybe_unused]] F s3 = vsplat(u, 0.f);
         if constexpr (DIST) {
-            // + 2 k1 [ p (uv.w) + t w + (u,v)(p.w) ] . nq          (perspective_fields.py:146-153)
             const F np_ = vfma(nx, px, ny * py);
-            const F pw = vfma(px, wx, vsplat(u, py * wy));
-            s2 = vfma(vfma(np_, uvw, vfma(t, nw, nuv * pw)), vsplat(u, k1x2), s2);
-            s3 = vfma(r2, np_, (t * 2.0f) * nuv);        // dq/dk1 = r2 p + 2 t (u,v)   (:170-180)
+            // + 2 k1 [ p (uv.w) + t w + (u,v)(p.w) ] . nq          (perspective_fields.py:146-153)
+            if constexpr (LOGF) {
+                s3 = vfma(r2, np_, (t * 2.0f) * nuv);    // dq/dk1 = r2 p + 2 t (u,v)   (:170-180)
+                s2 = vfma(s3, vsplat(u, -k1x2), s2);
+            } else {
+                const F pw = vfma(px, wx, vsplat(u, py * wy));
+                s2 = vfma(vfma(np_, uvw, vfma(t, nw, nuv * pw)), vsplat(u, k1x2), s2);
+                s3 = vfma(r2, np_, (t * 2.0f) * nuv);
+            }
         }
         const F rho = vfma(ux, ry, -(uy * rx));
         const F w0 = wgt * s0, w1 = wgt * s1, w2 = wgt * s2;
@@ -315,20 +334,27 @@ __device__ __forceinline__ void pixel_accumulate_fast(const PBlock& P, const Hub
         const F s = vfma(rayx, vsplat(u, P.ga), vfma(rayy, vsplat(u, P.gb), rnn * P.gc));
         const F sc = vclamp(s, -1.0f + 1e-6f, 1.0f - 1e-6f);
         const F rl = sin_halfpi(dlat) - sc;              // lm_optimizer.py:262,270-271
-        F wgt;
-        const F cost = huber(rl * rl, hk.inv_a2l, wgt);
-        wgt = wgt * cl;
-        acc[A_CL] = vfma(cost, cl, acc[A_CL]);
+        const F wgt = huber_accumulate(rl * rl, hk.inv_a2l, cl, acc[A_CL]);
         const F l0 = vfma(rayx, vsplat(u, P.T00), vfma(rayy, vsplat(u, P.T10), rnn * P.T20));
         const F l1 = vfma(rayx, vsplat(u, P.T01), vfma(rayy, vsplat(u, P.T11), rnn * P.T21));
         const F hx = vfma(-s, rayx, vsplat(u, P.ga)) * rnn, hy = vfma(-s, rayy, vsplat(u, P.gb)) * rnn;
         // ds/df = h.(e w - 2 k1 (u,v)(uv.w)),  ds/dk1 = h.(-r2 (u,v))     (perspective_fields.py:255-272)
-        const F hw = vfma(hx, wx, hy * wy);
-        F l2 = hw;
-        [[maybe_unused]] F hu = vsplat(u, 0.f);
-        if constexpr (DIST) {
+        F l2;
+        [[maybe_unused]] F hu = vsplat(u, 0.f), l3 = vsplat(u, 0.f);
+        if constexpr (LOGF) {
             hu = vfma(hx, u, hy * v);
-            l2 = vfma(e, hw, -((uvw * k1x2) * hu));
+            l2 = -hu;
+            if constexpr (DIST) {
+                l3 = -(hu * r2);
+                l2 = vfma(l3, vsplat(u, -k1x2), -(e * hu));
+            }
+        } else {
+            const F hw = vfma(hx, wx, hy * wy);
+            l2 = hw;
+            if constexpr (DIST) {
+                hu = vfma(hx, u, hy * v);
+                l2 = vfma(e, hw, -((uvw * k1x2) * hu));
+            }
         }
         const F w0 = wgt * l0, w1 = wgt * l1, w2 = wgt * l2;
         acc[A_G0 + 0] = vfma(w0, rl, acc[A_G0 + 0]);
@@ -341,7 +367,7 @@ __device__ __forceinline__ void pixel_accumulate_fast(const PBlock& P, const Hub
         acc[A_H00 + 5] = vfma(w1, l2, acc[A_H00 + 5]);
         acc[A_H00 + 7] = vfma(w2, l2, acc[A_H00 + 7]);
         if constexpr (DIST) {
-            const F l3 = -(hu * r2);
+            if constexpr (!LOGF) l3 = -(hu * r2);
             const F w3 = wgt * l3;
             acc[A_G0 + 3] = vfma(w3, rl, acc[A_G0 + 3]);
             acc[A_H00 + 3] = vfma(w0, l3, acc[A_H00 + 3]);
@@ -352,7 +378,7 @@ __device__ __forceinline__ void pixel_accumulate_fast(const PBlock& P, const Hub
     }
 }
 
-template <int MODEL, bool HAS_UP, typename F>
+template <int MODEL, bool HAS_UP, bool LOGF, typename F>
 __device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& hk, F xf, float yf, F dux, F duy,
                                                  F dlat, F cu, F cl, F (&acc)[Layout<MODEL>::NACC]) {
     constexpr bool DIST = MODEL != GCLM_PINHOLE;
@@ -360,9 +386,13 @@ __device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& 
     const F u = (xf - P.cx) * P.ifx;
     const float v = (yf - P.cy) * P.ify;                 // one image row per tile: v is lane-scalar
     const F r2 = vfma(u, u, vsplat(u, v * v));
-    const F wx = u * (-P.wfx);                           // d(uv)/d(focal parameter) = (wx, wy)
-    const float wy = -v * P.wfy;
-    const F uvw = vfma(u, wx, vsplat(u, v * wy));
+    [[maybe_unused]] F wx = vsplat(u, 0.f), uvw = vsplat(u, 0.f);
+    [[maybe_unused]] float wy = 0.f;
+    if constexpr (!LOGF) {                               // LOGF: w = -(u,v), see pixel_accumulate_fast
+        wx = u * (-P.wfx);                               // d(uv)/d(focal parameter) = (wx, wy)
+        wy = -v * P.wfy;
+        uvw = vfma(u, wx, vsplat(u, v * wy));
+    }
     Radial<F> R;
     radial_terms<MODEL>(P, r2, R);
 
@@ -381,37 +411,46 @@ __device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& 
         const F ux = qx * rn, uy = qy * rn;              // predicted up vector
         const F rx = dux - ux, ry = duy - uy;            // residual (lm_optimizer.py:266)
         const F x2 = vfma(rx, rx, ry * ry);
-        F wgt;
-        const F cost = huber(x2, hk.inv_a2u, wgt);
-        wgt = wgt * cu;
-        acc[A_CU] = vfma(cost, cu, acc[A_CU]);
+        const F wgt = huber_accumulate(x2, hk.inv_a2u, cu, acc[A_CU]);
         // rank-one Jacobian: s_k = (M nq) . dp/dtheta_k, nq = n/|q|, n = (-uy, ux);  rho = n . r
         const F nx = -uy * rn, ny = ux * rn;
         const F nuv = vfma(nx, u, ny * v);
-        const F nw = vfma(nx, wx, ny * wy);
+        [[maybe_unused]] F nw = vsplat(u, 0.f);
+        if constexpr (!LOGF) nw = vfma(nx, wx, ny * wy);
         F mx = nx, my = ny, muv = nuv, mw = nw;
         if constexpr (DIST) {
             const F c2 = R.s1x2 * nuv;
             mx = vfma(R.s, nx, c2 * u);
             my = vfma(R.s, ny, c2 * v);
             muv = vfma(mx, u, my * v);
-            mw = vfma(mx, wx, my * wy);
+            if constexpr (!LOGF) mw = vfma(mx, wx, my * wy);
         }
         F s[PN];
         // dp/ddelta_k = (T0k - u T2k, T1k - v T2k)  =>  s_k = m.T[0:2,k] - (m.uv) T2k
         s[0] = vfma(mx, vsplat(u, P.T00), vfma(my, vsplat(u, P.T10), muv * (-P.T20)));
         s[1] = vfma(mx, vsplat(u, P.T01), vfma(my, vsplat(u, P.T11), muv * (-P.T21)));
-        s[2] = mw * (-P.gc);                             // dp/df = -c w
+        s[2] = LOGF ? muv * P.gc : mw * (-P.gc);         // dp/df = -c w
         if constexpr (DIST) {
             const F np_ = vfma(nx, px, ny * py);
-            const F pw = vfma(px, wx, vsplat(u, py * wy));
             // + [p (off.w) + off (p.w)] . nq + t (Joff w) . nq            (perspective_fields.py:146-153)
-            if constexpr (MODEL == GCLM_SIMPLE_DIVISIONAL) {     // jd carries the reference's own guards
-                s[2] = vfma(R.s1x2, vfma(np_, uvw, nuv * pw), s[2]);
-                s[2] = vfma(t, vfma(R.jd, nw, R.s2x4 * (uvw * nuv)), s[2]);
-            } else {                                             // polynomial models: jd == 2 s1
-                s[2] = vfma(R.s1x2, vfma(np_, uvw, vfma(t, nw, nuv * pw)), s[2]);
-                if constexpr (MODEL == GCLM_RADIAL) s[2] = vfma(R.s2x4 * t, uvw * nuv, s[2]);
+            if constexpr (LOGF) {                                // uv.w = -r2, n.w = -n.uv, p.w = -t
+                const F a_ = np_ * r2, b_ = t * nuv;
+                if constexpr (MODEL == GCLM_SIMPLE_DIVISIONAL) {
+                    s[2] = vfma(-R.s1x2, a_ + b_, s[2]);
+                    s[2] = vfma(-b_, vfma(R.s2x4, r2, R.jd), s[2]);
+                } else {
+                    s[2] = vfma(-R.s1x2, vfma(b_, vsplat(u, 2.0f), a_), s[2]);
+                    if constexpr (MODEL == GCLM_RADIAL) s[2] = vfma(-(R.s2x4 * r2), b_, s[2]);
+                }
+            } else {
+                const F pw = vfma(px, wx, vsplat(u, py * wy));
+                if constexpr (MODEL == GCLM_SIMPLE_DIVISIONAL) {     // jd carries the reference's own guards
+                    s[2] = vfma(R.s1x2, vfma(np_, uvw, nuv * pw), s[2]);
+                    s[2] = vfma(t, vfma(R.jd, nw, R.s2x4 * (uvw * nuv)), s[2]);
+                } else {                                             // polynomial models: jd == 2 s1
+                    s[2] = vfma(R.s1x2, vfma(np_, uvw, vfma(t, nw, nuv * pw)), s[2]);
+                    if constexpr (MODEL == GCLM_RADIAL) s[2] = vfma(R.s2x4 * t, uvw * nuv, s[2]);
+                }
             }
 #pragma unroll
             for (int j = 0; j < ND; ++j)                 // dq/dk_j = (ds/dk_j) p + 2 (ds1/dk_j) t (u,v)   (:170-180)
@@ -433,22 +472,29 @@ __device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& 
         const F s_ = vfma(rayx, vsplat(u, P.ga), vfma(rayy, vsplat(u, P.gb), rnn * P.gc));
         const F sc = vclamp(s_, -1.0f + 1e-6f, 1.0f - 1e-6f);
         const F rl = sin_halfpi(dlat) - sc;              // lm_optimizer.py:262,270-271
-        F wgt;
-        const F cost = huber(rl * rl, hk.inv_a2l, wgt);
-        wgt = wgt * cl;
-        acc[A_CL] = vfma(cost, cl, acc[A_CL]);
+        const F wgt = huber_accumulate(rl * rl, hk.inv_a2l, cl, acc[A_CL]);
         F l[PN];
         l[0] = vfma(rayx, vsplat(u, P.T00), vfma(rayy, vsplat(u, P.T10), rnn * P.T20));
         l[1] = vfma(rayx, vsplat(u, P.T01), vfma(rayy, vsplat(u, P.T11), rnn * P.T21));
         const F hx = vfma(-s_, rayx, vsplat(u, P.ga)) * rnn, hy = vfma(-s_, rayy, vsplat(u, P.gb)) * rnn;
         // ds/df = tau (h.w) + 2 tau1 (uv.w)(h.uv),  ds/dk_j = (dtau/dk_j)(h.uv)   (perspective_fields.py:255-272)
-        const F hw = vfma(hx, wx, hy * wy);
-        l[2] = hw;
-        if constexpr (DIST) {
+        if constexpr (LOGF) {                            // h.w = -h.uv, uv.w = -r2
             const F hu = vfma(hx, u, hy * v);
-            l[2] = vfma(R.tau, hw, (R.tau1x2 * uvw) * hu);
+            l[2] = -hu;
+            if constexpr (DIST) {
+                l[2] = -(hu * vfma(R.tau1x2, r2, R.tau));
 #pragma unroll
-            for (int j = 0; j < ND; ++j) l[3 + j] = R.dtau[j] * hu;
+                for (int j = 0; j < ND; ++j) l[3 + j] = R.dtau[j] * hu;
+            }
+        } else {
+            const F hw = vfma(hx, wx, hy * wy);
+            l[2] = hw;
+            if constexpr (DIST) {
+                const F hu = vfma(hx, u, hy * v);
+                l[2] = vfma(R.tau, hw, (R.tau1x2 * uvw) * hu);
+#pragma unroll
+                for (int j = 0; j < ND; ++j) l[3 + j] = R.dtau[j] * hu;
+            }
         }
         accumulate<MODEL>(acc, l, wgt, rl);
     }
@@ -497,7 +543,7 @@ struct Lane<1> {
     static __device__ __forceinline__ F xcoord(int x, int) { return (float)x; }
 };
 
-template <int MODEL, bool HAS_UP, bool HAS_UPC, bool HAS_LATC, int VEC>
+template <int MODEL, bool HAS_UP, bool HAS_UPC, bool HAS_LATC, bool LOGF, int VEC>
 // launch bounds: radial / simple_divisional are held to 168 VGPRs (3 waves per SIMD); the two BASELINE models
 // reach 96 / 128 on their own
 __global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL >= GCLM_RADIAL) ? 3 : GCLM_MIN_WAVES) void sweep_kernel(
@@ -544,6 +590,9 @@ __global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL >= GCLM_RADIAL) ? 3 : GC
         const V vlat = L::ld(lat, unit);
         if constexpr (HAS_UP && HAS_UPC) vcu = L::ld(upc, unit);
         if constexpr (HAS_LATC) vcl = L::ld(latc, unit);
+        // keep every load of the iteration ahead of the math: left alone, the scheduler sinks loads next to
+        // their first use to save registers in some instantiations (load -> wait -> use, five times over)
+        __builtin_amdgcn_sched_barrier(0);
         const float yf = (float)y;
 #if GCLM_NOMATH     // measurement only: the memory-system ceiling of this exact access pattern
 #pragma unroll
@@ -556,11 +605,11 @@ __global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL >= GCLM_RADIAL) ? 3 : GC
 #pragma unroll
         for (int k = 0; k < L::kPairs; ++k) {
             if constexpr (MODEL == GCLM_PINHOLE || MODEL == GCLM_SIMPLE_RADIAL)
-                pixel_accumulate_fast<MODEL, HAS_UP, F>(P, hk, L::xcoord(x, k), yf, HAS_UP ? L::get(vux, k) : F(0.f),
+                pixel_accumulate_fast<MODEL, HAS_UP, LOGF, F>(P, hk, L::xcoord(x, k), yf, HAS_UP ? L::get(vux, k) : F(0.f),
                                                         HAS_UP ? L::get(vuy, k) : F(0.f), L::get(vlat, k),
                                                         L::get(vcu, k), L::get(vcl, k), acc);
             else
-                pixel_accumulate<MODEL, HAS_UP, F>(P, hk, L::xcoord(x, k), yf, HAS_UP ? L::get(vux, k) : F(0.f),
+                pixel_accumulate<MODEL, HAS_UP, LOGF, F>(P, hk, L::xcoord(x, k), yf, HAS_UP ? L::get(vux, k) : F(0.f),
                                                    HAS_UP ? L::get(vuy, k) : F(0.f), L::get(vlat, k), L::get(vcu, k),
                                                    L::get(vcl, k), acc);
         }
@@ -596,8 +645,13 @@ template <int MODEL, int VEC>
 hipError_t dispatch(const SweepArgs& a, hipStream_t s) {
     const dim3 grid(a.nchunks, a.B), block(kBlock);
     const bool up = a.up != nullptr, upc = up && a.upc != nullptr, latc = a.latc != nullptr;
-#define GCLM_LAUNCH(U, UC, LC) \
-    hipLaunchKernelGGL((sweep_kernel<MODEL, U, UC, LC, VEC>), grid, block, 0, s, a)
+    // the log-focal specialisation only for the vector path (the scalar path is the odd-shape fallback)
+    const bool logf = VEC == 4 && a.log_focal != 0 && GCLM_LOGF;
+#define GCLM_LAUNCH(U, UC, LC)                                                                          \
+    do {                                                                                                \
+        if (logf) hipLaunchKernelGGL((sweep_kernel<MODEL, U, UC, LC, VEC == 4, VEC>), grid, block, 0, s, a); \
+        else hipLaunchKernelGGL((sweep_kernel<MODEL, U, UC, LC, false, VEC>), grid, block, 0, s, a);    \
+    } while (0)
     if (up) {
         if (upc) { if (latc) GCLM_LAUNCH(true, true, true); else GCLM_LAUNCH(true, true, false); }
         else     { if (latc) GCLM_LAUNCH(true, false, true); else GCLM_LAUNCH(true, false, false); }
