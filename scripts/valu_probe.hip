@@ -16,6 +16,9 @@ __global__ __launch_bounds__(256) void probe(float* out, long long* cyc, float s
     f2 a[8];
     float b[8];
     for (int i = 0; i < 8; ++i) { a[i] = f2{seed + i, seed - i}; b[i] = seed * (i + 1); }
+    f2 x[8], z[8];
+    float xs[8], zs[8];
+    for (int i = 0; i < 8; ++i) { x[i] = f2{seed * i, seed + 2 * i}; z[i] = f2{seed - 3 * i, seed * 0.1f * i}; xs[i] = seed * 3 * i; zs[i] = seed - 5 * i; }
     const f2 k = f2{seed * 0.5f, seed * 0.25f};
     const float ks = seed * 0.5f;
     const long long t0 = clock64();
@@ -56,12 +59,32 @@ __global__ __launch_bounds__(256) void probe(float* out, long long* cyc, float s
 #define OP(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %1 op_sel_hi:[1,0,0] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "+v"(a[i]) : "v"(k));
             BODY4(OP)
 #undef OP
+        } else if constexpr (KIND == 8) {       // three distinct 64-bit sources (what real code looks like)
+#define OP(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x[i]), "v"(z[i]));
+            BODY4(OP)
+#undef OP
+        } else if constexpr (KIND == 9) {
+#define OP(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(b[i]) : "v"(xs[i]), "v"(zs[i]));
+            BODY4(OP)
+#undef OP
+        } else if constexpr (KIND == 10) {
+#define OP(i) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(a[i]) : "v"(x[i]), "v"(z[i]));
+            BODY4(OP)
+#undef OP
+        } else if constexpr (KIND == 11) {
+#define OP(i) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(b[i]) : "v"(xs[i]), "v"(zs[i]));
+            BODY4(OP)
+#undef OP
+        } else if constexpr (KIND == 12) {      // same FLOPs as KIND 8, unpacked
+#define OP(i) asm volatile("v_fma_f32 %0, %2, %4, %0\n v_fma_f32 %1, %3, %5, %1" : "+v"(b[i]), "+v"(xs[i]) : "v"(zs[i]), "v"(zs[(i + 1) & 7]), "v"(a[i].x), "v"(a[i].y));
+            REP8(OP) REP8(OP)
+#undef OP
         }
     }
     const long long t1 = clock64();
     const long long w1 = wall_clock64();
     float s = 0.f;
-    for (int i = 0; i < 8; ++i) s += a[i].x + a[i].y + b[i];
+    for (int i = 0; i < 8; ++i) s += a[i].x + a[i].y + b[i] + x[i].x + z[i].y + xs[i] + zs[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (threadIdx.x == 0) { cyc[2 * blockIdx.x] = t1 - t0; cyc[2 * blockIdx.x + 1] = w1 - w0; }
 }
@@ -94,7 +117,7 @@ void run(const char* name, int n_instr, int waves_per_simd) {
 }
 
 int main() {
-    for (int occ : {1, 4}) {
+    for (int occ : {1, 4, 8}) {
         run<0>("v_fma_f32", 32, occ);
         run<1>("v_pk_fma_f32", 32, occ);
         run<7>("v_pk_fma_f32 (mods)", 32, occ);
@@ -103,6 +126,11 @@ int main() {
         run<3>("v_min_f32", 32, occ);
         run<4>("v_rsq_f32", 32, occ);
         run<5>("mix 24 pk_fma/16 pk_mul/16 min", 56, occ);
+        run<8>("v_pk_fma_f32 3 distinct src", 32, occ);
+        run<9>("v_fma_f32 3 distinct src", 32, occ);
+        run<12>("2x v_fma_f32 (= 1 pk_fma)", 32, occ);
+        run<10>("v_pk_mul_f32 distinct", 32, occ);
+        run<11>("v_mul_f32 distinct", 32, occ);
     }
     return 0;
 }
