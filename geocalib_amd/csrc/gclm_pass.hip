@@ -321,40 +321,39 @@ __device__ __forceinline__ void pixel_accumulate_fast(const PBlock& P, const Hub
         }
     }
 
-    {   // latitude
-        F Px = u, Py = vsplat(u, v), e = vsplat(u, 1.0f);
+    {   // latitude.  ray = (e u, e v, 1) / n; everything below needs the ray only through dot products with
+        // per-image vectors, so it is never formed:  ray.x = ern (x_xy.uv) + rnn x_z,  ern = e/n, rnn = 1/n
+        F e = vsplat(u, 1.0f), er2 = r2;
         if constexpr (DIST) {
             e = vfma(r2, vsplat(u, -P.k1), vsplat(u, 1.0f));
-            Px = e * u;
-            Py = e * v;
+            er2 = e * r2;
         }
-        const F nn = vfma(Px, Px, vfma(Py, Py, vsplat(u, 1.0f)));
+        const F nn = DIST ? vfma(e, er2, vsplat(u, 1.0f)) : r2 + 1.0f;      // |(e u, e v, 1)|^2
         const F rnn = vrsq(nn);
-        const F rayx = Px * rnn, rayy = Py * rnn;        // rayz = rnn
-        const F s = vfma(rayx, vsplat(u, P.ga), vfma(rayy, vsplat(u, P.gb), rnn * P.gc));
+        const F ern = DIST ? e * rnn : rnn;
+        const F guv = vfma(u, vsplat(u, P.ga), vsplat(u, v * P.gb));          // g_xy . uv
+        const F s = vfma(ern, guv, rnn * P.gc);                              // ray . g
         const F sc = vclamp(s, -1.0f + 1e-6f, 1.0f - 1e-6f);
         const F rl = sin_halfpi(dlat) - sc;              // lm_optimizer.py:262,270-271
         const F wgt = huber_accumulate(rl * rl, hk.inv_a2l, cl, acc[A_CL]);
-        const F l0 = vfma(rayx, vsplat(u, P.T00), vfma(rayy, vsplat(u, P.T10), rnn * P.T20));
-        const F l1 = vfma(rayx, vsplat(u, P.T01), vfma(rayy, vsplat(u, P.T11), rnn * P.T21));
-        const F hx = vfma(-s, rayx, vsplat(u, P.ga)) * rnn, hy = vfma(-s, rayy, vsplat(u, P.gb)) * rnn;
-        // ds/df = h.(e w - 2 k1 (u,v)(uv.w)),  ds/dk1 = h.(-r2 (u,v))     (perspective_fields.py:255-272)
+        const F l0 = vfma(ern, vfma(u, vsplat(u, P.T00), vsplat(u, v * P.T10)), rnn * P.T20);   // ray . T[:,0]
+        const F l1 = vfma(ern, vfma(u, vsplat(u, P.T01), vsplat(u, v * P.T11)), rnn * P.T21);
+        // h = (g_xy - s ray_xy)/n;  ds/df = h.(e w - 2 k1 (u,v)(uv.w)),  ds/dk1 = h.(-r2 (u,v))   (perspective_fields.py:255-272)
+        //   h.uv = rnn (g_xy.uv - s ern r2),   h.w = rnn (g_xy.w - s ern (uv.w))
         F l2;
         [[maybe_unused]] F hu = vsplat(u, 0.f), l3 = vsplat(u, 0.f);
+        if constexpr (LOGF || DIST) hu = vfma(-s, DIST ? er2 * rnn : r2 * rnn, guv) * rnn;
         if constexpr (LOGF) {
-            hu = vfma(hx, u, hy * v);
             l2 = -hu;
             if constexpr (DIST) {
                 l3 = -(hu * r2);
                 l2 = vfma(l3, vsplat(u, -k1x2), -(e * hu));
             }
         } else {
-            const F hw = vfma(hx, wx, hy * wy);
+            const F gw = vfma(wx, vsplat(u, P.ga), vsplat(u, wy * P.gb));
+            const F hw = vfma(-s, ern * uvw, gw) * rnn;
             l2 = hw;
-            if constexpr (DIST) {
-                hu = vfma(hx, u, hy * v);
-                l2 = vfma(e, hw, -((uvw * k1x2) * hu));
-            }
+            if constexpr (DIST) l2 = vfma(e, hw, -((uvw * k1x2) * hu));
         }
         const F w0 = wgt * l0, w1 = wgt * l1, w2 = wgt * l2;
         acc[A_G0 + 0] = vfma(w0, rl, acc[A_G0 + 0]);
@@ -460,43 +459,80 @@ __device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& 
         accumulate<MODEL>(acc, s, wgt, rho);
     }
 
-    {   // latitude
-        F Px = u, Py = vsplat(u, v);
-        if constexpr (DIST) {
-            Px = R.tau * u;
-            Py = R.tau * v;
-        }
-        const F nn = vfma(Px, Px, vfma(Py, Py, vsplat(u, 1.0f)));
-        const F rnn = vrsq(nn);
-        const F rayx = Px * rnn, rayy = Py * rnn;        // rayz = rnn
-        const F s_ = vfma(rayx, vsplat(u, P.ga), vfma(rayy, vsplat(u, P.gb), rnn * P.gc));
-        const F sc = vclamp(s_, -1.0f + 1e-6f, 1.0f - 1e-6f);
-        const F rl = sin_halfpi(dlat) - sc;              // lm_optimizer.py:262,270-271
-        const F wgt = huber_accumulate(rl * rl, hk.inv_a2l, cl, acc[A_CL]);
-        F l[PN];
-        l[0] = vfma(rayx, vsplat(u, P.T00), vfma(rayy, vsplat(u, P.T10), rnn * P.T20));
-        l[1] = vfma(rayx, vsplat(u, P.T01), vfma(rayy, vsplat(u, P.T11), rnn * P.T21));
-        const F hx = vfma(-s_, rayx, vsplat(u, P.ga)) * rnn, hy = vfma(-s_, rayy, vsplat(u, P.gb)) * rnn;
-        // ds/df = tau (h.w) + 2 tau1 (uv.w)(h.uv),  ds/dk_j = (dtau/dk_j)(h.uv)   (perspective_fields.py:255-272)
-        if constexpr (LOGF) {                            // h.w = -h.uv, uv.w = -r2
-            const F hu = vfma(hx, u, hy * v);
-            l[2] = -hu;
+    // The dot-product form of the latitude block is 2-3 % faster for simple_divisional (and the two fast-path
+    // models) but pushes radial (24 accumulator pairs) past 168 VGPRs into spills: -3 % there, so it keeps rays.
+    if constexpr (MODEL != GCLM_RADIAL) {
+        {   // latitude (ray = (tau u, tau v, 1)/n only through dot products, see pixel_accumulate_fast)
+            const F tr2 = DIST ? R.tau * r2 : r2;
+            const F nn = DIST ? vfma(R.tau, tr2, vsplat(u, 1.0f)) : r2 + 1.0f;
+            const F rnn = vrsq(nn);
+            const F trn = DIST ? R.tau * rnn : rnn;
+            const F guv = vfma(u, vsplat(u, P.ga), vsplat(u, v * P.gb));
+            const F s_ = vfma(trn, guv, rnn * P.gc);
+            const F sc = vclamp(s_, -1.0f + 1e-6f, 1.0f - 1e-6f);
+            const F rl = sin_halfpi(dlat) - sc;              // lm_optimizer.py:262,270-271
+            const F wgt = huber_accumulate(rl * rl, hk.inv_a2l, cl, acc[A_CL]);
+            F l[PN];
+            l[0] = vfma(trn, vfma(u, vsplat(u, P.T00), vsplat(u, v * P.T10)), rnn * P.T20);
+            l[1] = vfma(trn, vfma(u, vsplat(u, P.T01), vsplat(u, v * P.T11)), rnn * P.T21);
+            // ds/df = tau (h.w) + 2 tau1 (uv.w)(h.uv),  ds/dk_j = (dtau/dk_j)(h.uv)   (perspective_fields.py:255-272)
+            //   h.uv = rnn (g_xy.uv - s trn r2),   h.w = rnn (g_xy.w - s trn (uv.w))
+            [[maybe_unused]] F hu = vsplat(u, 0.f);
+            if constexpr (LOGF || DIST) hu = vfma(-s_, tr2 * rnn, guv) * rnn;
+            if constexpr (LOGF) {                            // h.w = -h.uv, uv.w = -r2
+                l[2] = -hu;
+                if constexpr (DIST) l[2] = -(hu * vfma(R.tau1x2, r2, R.tau));
+            } else {
+                const F gw = vfma(wx, vsplat(u, P.ga), vsplat(u, wy * P.gb));
+                const F hw = vfma(-s_, trn * uvw, gw) * rnn;
+                l[2] = hw;
+                if constexpr (DIST) l[2] = vfma(R.tau, hw, (R.tau1x2 * uvw) * hu);
+            }
             if constexpr (DIST) {
-                l[2] = -(hu * vfma(R.tau1x2, r2, R.tau));
-#pragma unroll
+    #pragma unroll
                 for (int j = 0; j < ND; ++j) l[3 + j] = R.dtau[j] * hu;
             }
-        } else {
-            const F hw = vfma(hx, wx, hy * wy);
-            l[2] = hw;
+            accumulate<MODEL>(acc, l, wgt, rl);
+        }
+    } else {
+        {   // latitude
+            F Px = u, Py = vsplat(u, v);
             if constexpr (DIST) {
+                Px = R.tau * u;
+                Py = R.tau * v;
+            }
+            const F nn = vfma(Px, Px, vfma(Py, Py, vsplat(u, 1.0f)));
+            const F rnn = vrsq(nn);
+            const F rayx = Px * rnn, rayy = Py * rnn;        // rayz = rnn
+            const F s_ = vfma(rayx, vsplat(u, P.ga), vfma(rayy, vsplat(u, P.gb), rnn * P.gc));
+            const F sc = vclamp(s_, -1.0f + 1e-6f, 1.0f - 1e-6f);
+            const F rl = sin_halfpi(dlat) - sc;              // lm_optimizer.py:262,270-271
+            const F wgt = huber_accumulate(rl * rl, hk.inv_a2l, cl, acc[A_CL]);
+            F l[PN];
+            l[0] = vfma(rayx, vsplat(u, P.T00), vfma(rayy, vsplat(u, P.T10), rnn * P.T20));
+            l[1] = vfma(rayx, vsplat(u, P.T01), vfma(rayy, vsplat(u, P.T11), rnn * P.T21));
+            const F hx = vfma(-s_, rayx, vsplat(u, P.ga)) * rnn, hy = vfma(-s_, rayy, vsplat(u, P.gb)) * rnn;
+            // ds/df = tau (h.w) + 2 tau1 (uv.w)(h.uv),  ds/dk_j = (dtau/dk_j)(h.uv)   (perspective_fields.py:255-272)
+            if constexpr (LOGF) {                            // h.w = -h.uv, uv.w = -r2
                 const F hu = vfma(hx, u, hy * v);
-                l[2] = vfma(R.tau, hw, (R.tau1x2 * uvw) * hu);
-#pragma unroll
-                for (int j = 0; j < ND; ++j) l[3 + j] = R.dtau[j] * hu;
+                l[2] = -hu;
+                if constexpr (DIST) {
+                    l[2] = -(hu * vfma(R.tau1x2, r2, R.tau));
+    #pragma unroll
+                    for (int j = 0; j < ND; ++j) l[3 + j] = R.dtau[j] * hu;
+                }
+            } else {
+                const F hw = vfma(hx, wx, hy * wy);
+                l[2] = hw;
+                if constexpr (DIST) {
+                    const F hu = vfma(hx, u, hy * v);
+                    l[2] = vfma(R.tau, hw, (R.tau1x2 * uvw) * hu);
+    #pragma unroll
+                    for (int j = 0; j < ND; ++j) l[3 + j] = R.dtau[j] * hu;
+                }
             }
+            accumulate<MODEL>(acc, l, wgt, rl);
         }
-        accumulate<MODEL>(acc, l, wgt, rl);
     }
 }
 
@@ -546,7 +582,7 @@ struct Lane<1> {
 template <int MODEL, bool HAS_UP, bool HAS_UPC, bool HAS_LATC, bool LOGF, int VEC>
 // launch bounds: radial / simple_divisional are held to 168 VGPRs (3 waves per SIMD); the two BASELINE models
 // reach 96 / 128 on their own
-__global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL >= GCLM_RADIAL) ? 3 : GCLM_MIN_WAVES) void sweep_kernel(
+__global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL >= GCLM_RADIAL) ? 3 : (VEC == 4 && MODEL == GCLM_SIMPLE_RADIAL) ? 4 : GCLM_MIN_WAVES) void sweep_kernel(
     const SweepArgs a) {
     if (stop_fired_before(a.ctrl, a.stop_step)) return;   // batch-global early stop, no host sync
     constexpr int NACC = Layout<MODEL>::NACC;
