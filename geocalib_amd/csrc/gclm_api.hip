@@ -1,7 +1,7 @@
 // gclm_api.hip -- C ABI of libgeocalib_hip.so (include/gclm.h) and the launch sequence of a solve.
 //
 // A solve is 2*num_steps+4 asynchronous launches on the caller's stream and no host round trip:
-//   init | { sweep(theta_i) ; update_i [; decide_i] } x num_steps | prep_final ; sweep(theta_final, rpf) ; finalize
+//   init | { sweep(theta_i) ; update_i } x num_steps | prep_final ; sweep(theta_final, rpf) ; finalize
 // (the reference syncs twice per step: H,G -> CPU Cholesky -> device, and torch.allclose).
 #include <cstdarg>
 #include <cstdio>

@@ -22,6 +22,9 @@
 //   LAT  P=tau (u,v); ray=(P,1)/sqrt(|P|^2+1); s=ray.g; r_lat=sin(lat_data)-clamp(s)
 //        ds/d(delta_k)=ray.T[:,k];  ds/df = tau (h.w) + 2 tau1 (uv.w)(h.uv);  ds/dk_j = (dtau/dk_j)(h.uv),
 //        h=(g_xy-s ray_xy)/sqrt(|P|^2+1),  w=(-u wfx,-v wfy)
+//        (evaluated through dot products, the ray is never formed: ray.x = (tau/n)(x_xy.uv) + x_z/n)
+//   log-focal loop sweeps (LOGF): w = -(u,v), so x.w = -(x.uv) and the focal columns collapse, see
+//   pixel_accumulate_fast.
 //   pinhole: s = tau = 1.  simple_radial: s = 1+k1 r2, tau = 1-k1 r2.  radial: s = 1+k1 r2+k2 r4,
 //   tau = 1-k1 r2+(3k1^2-k2) r4.  simple_divisional: s = (1-sqrt(1-4k r2))/(2k r2), tau = 1/(1+k r2)
 //   with the reference's own guards (camera.py:829-940).
@@ -34,8 +37,9 @@
 // workgroup is written (no atomics: bit-reproducible).  No MFMA: the contraction is N x P -> P x P,
 // P <= 5.
 //
-// Arithmetic: PMC counters (profiles/r01_pmc_sq_*) show the sweep is VALU-issue-bound as soon as
-// it approaches ~6 TB/s, so the float4 path computes PIXEL PAIRS in packed fp32 (v_pk_fma_f32 /
+// Arithmetic: PMC counters (profiles/r01_pmc_sq_*) show the sweep is fp32-VALU-bound as soon as
+// it approaches ~6 TB/s (scripts/valu_probe.hip: a packed op costs ~1.8x a scalar one, i.e. the bound is
+// FLOPs at 32 lanes/SIMD/cycle), so every flop taken out of the pixel body counts; the float4 path computes PIXEL PAIRS in packed fp32 (v_pk_fma_f32 /
 // v_pk_mul_f32 / v_pk_add_f32: two pixels per instruction) -- written explicitly on a 2-wide vector
 // type so the pairs live in adjacent registers straight out of the dwordx4 loads (LLVM's SLP
 // vectoriser finds some of these pairs on its own but pays for them with register shuffles and 2x
