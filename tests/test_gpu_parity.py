@@ -436,11 +436,13 @@ def test_randomised_configurations_against_oracle(dev, oracle):
     """Seeded fuzz: random shapes (vector and scalar paths), batch sizes, camera models, conf knobs, missing
     confidences / up field, priors and scales -- the HIP path against the oracle on identical inputs."""
     from oracle import synth
-    rng = np.random.default_rng(2024)
-    worst = {}
-    for case in range(40):
+    rng = np.random.default_rng(int(os.environ.get("GCLM_FUZZ_SEED", "2024")))     # soak: GCLM_FUZZ_CASES=400
+    worst, undetermined = {}, 0
+    for case in range(int(os.environ.get("GCLM_FUZZ_CASES", "40"))):
         model = ALL_MODELS[rng.integers(0, 3)]                      # simple_divisional has its own loose tests
         H, W = int(rng.integers(24, 90)), int(rng.integers(24, 120))
+        if rng.random() < 0.1:                                      # many chunk records per image: striped reduction
+            H, W = int(rng.integers(200, 300)), int(rng.integers(260, 340))
         if rng.random() < 0.5:
             W = W // 4 * 4
         B = int(rng.integers(1, 6))
@@ -470,16 +472,32 @@ def test_randomised_configurations_against_oracle(dev, oracle):
         if shared:
             conf |= {"shared_intrinsics": True, "early_stop": False}
         ref = oracle.solve(data, conf, precision="f32")
+        ref64 = oracle.solve(data, conf, precision="f64")
         out = run(conf, data, dev)
-        # unconverged / ill-conditioned draws (few steps, tiny images) amplify rounding: gate on the
-        # update-direction level, and tighter where the oracle itself says the problem is well determined
-        rel_f = np.abs(out["camera"][:, 2:4] / ref["camera"][:, 2:4] - 1).max()
-        dg = np.abs(out["gravity"] - ref["gravity"]).max()
-        dk = np.abs(out["camera"][:, 6:] - ref["camera"][:, 6:]).max()
-        dc = np.abs(out["final_cost"] - ref["final_cost"]).max() / max(np.abs(ref["final_cost"]).max(), 1e-7)   # noise-free draws: cost ~ 1e-14
-        worst[case] = (rel_f, dg, dk, dc)
-        assert rel_f < 2e-3 and dg < 2e-3 and dk < 5e-3 and dc < 2e-3, (case, model, (H, W), B, conf, worst[case])
+
+        def spread(a, b):
+            rel_f = np.abs(a["camera"][:, 2:4] / b["camera"][:, 2:4] - 1).max()
+            dg = np.abs(a["gravity"] - b["gravity"]).max()
+            dk = np.abs(a["camera"][:, 6:] - b["camera"][:, 6:]).max()
+            # noise-free draws end at costs ~1e-9 that are pure rounding: measure against the problem's own scale
+            floor = max(1e-7, 1e-3 * np.abs(b["initial_cost"]).max())
+            dc = np.abs(a["final_cost"] - b["final_cost"]).max() / max(np.abs(b["final_cost"]).max(), floor)
+            return np.array([rel_f, dg, dk, dc], np.float64)
+
+        # unconverged / ill-conditioned draws (few steps, tiny images at the focal clamp, radial k2 on a sliver of an
+        # image, noise-free costs ~1e-8) amplify rounding chaotically: where the oracle itself moves by more than
+        # 1e-3 between float32 and float64 the draw only has to stay finite; elsewhere the gate is tight
+        # (plus what the oracle moves).
         assert np.array_equal(out["camera"][:, [0, 1, 4, 5]], ref["camera"][:, [0, 1, 4, 5]])
+        assert all(np.isfinite(out[k]).all() for k in ("camera", "gravity", "final_cost"))
+        own = spread(ref, ref64)
+        if own.max() > 1e-3:
+            undetermined += 1
+            continue
+        worst[case] = spread(out, ref)
+        tol = np.array([2e-3, 2e-3, 5e-3, 2e-3]) + 10.0 * own
+        assert (worst[case] < tol).all(), (case, model, (H, W), B, conf, worst[case], tol)
+    assert undetermined <= 0.2 * (case + 1), undetermined
     med = np.median(np.array(list(worst.values())), axis=0)
     assert med[0] < 2e-5 and med[1] < 2e-5 and med[3] < 2e-5, med
 
