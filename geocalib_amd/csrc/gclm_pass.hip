@@ -52,6 +52,9 @@
 #ifndef GCLM_LOGF
 #define GCLM_LOGF 1            // A/B switch: 0 = always the general focal-column code
 #endif
+#ifndef GCLM_XCD_REMAP
+#define GCLM_XCD_REMAP 0
+#endif
 #ifndef GCLM_NT_LOADS
 #define GCLM_NT_LOADS 1
 #endif
@@ -590,7 +593,20 @@ __global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL >= GCLM_RADIAL) ? 3 : (V
     const SweepArgs a) {
     if (stop_fired_before(a.ctrl, a.stop_step)) return;   // batch-global early stop, no host sync
     constexpr int NACC = Layout<MODEL>::NACC;
+#if GCLM_XCD_REMAP      // A/B switch: each XCD (block id % 8) walks a contiguous eighth of the batch
+    int b = blockIdx.y, chunk = blockIdx.x;
+    {
+        const unsigned total = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+        if ((total & 7u) == 0) {
+            const unsigned nid = (lin & 7u) * (total >> 3) + (lin >> 3);
+            b = (int)(nid / gridDim.x);
+            chunk = (int)(nid - (unsigned)b * gridDim.x);
+        }
+    }
+    const int tid = threadIdx.x;
+#else
     const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+#endif
     const PBlock P = a.pb[b];                            // workgroup-uniform -> scalar loads
     HuberK hk;
     hk.a2u = a.up_scale * a.up_scale;
