@@ -423,6 +423,15 @@ int gclm_shared_finish(gclm_handle* h, float* d_info_out, void* stream) {
     return 0;
 }
 
+int gclm_jacobian_fields(int camera_model, const float* d_cam, const float* d_grav, int B, int H, int W,
+                         int spherical, int log_focal, float* d_J_up, float* d_J_lat, void* stream) {
+    if (!d_cam || !d_grav || (!d_J_up && !d_J_lat) || B < 0 || H <= 0 || W <= 0) return -3;
+    if (camera_model < GCLM_PINHOLE || camera_model > GCLM_SIMPLE_DIVISIONAL || B > 65535) return -3;
+    hipError_t e = launch_jacobian_fields(camera_model, d_cam, d_grav, B, H, W, spherical, log_focal, d_J_up, d_J_lat,
+                                          static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : -10;
+}
+
 int gclm_upsample_fields(const float* d_src, int planes, int h, int w, int H, int W, float* d_dst, void* stream) {
     if (!d_src || !d_dst || planes < 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return -3;
     hipError_t e = launch_upsample(d_src, planes, h, w, H, W, d_dst, static_cast<hipStream_t>(stream));

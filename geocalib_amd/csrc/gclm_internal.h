@@ -89,6 +89,8 @@ struct Geometry {          // how a sweep is cut into blocks
 Geometry plan_geometry(int B, int H, int W, bool aligned16);
 
 // gclm_pass.hip
+hipError_t launch_jacobian_fields(int camera_model, const float* d_cam, const float* d_grav, int B, int H, int W,
+                                  int spherical, int log_focal, float* d_J_up, float* d_J_lat, hipStream_t s);
 hipError_t launch_sweep(int camera_model, const SweepArgs& a, hipStream_t s);
 
 // gclm_update.hip

@@ -45,6 +45,7 @@
 // vectoriser finds some of these pairs on its own but pays for them with register shuffles and 2x
 // the VGPRs; it is switched off for this file, see the Makefile).
 #include "gclm_internal.h"
+#include "gclm_device.h"
 
 #ifndef GCLM_MIN_WAVES
 #define GCLM_MIN_WAVES 1
@@ -384,9 +385,13 @@ __device__ __forceinline__ void pixel_accumulate_fast(const PBlock& P, const Hub
     }
 }
 
-template <int MODEL, bool HAS_UP, bool LOGF, typename F>
+// EMIT (scalar instantiation only): instead of accumulating, write the per-pixel Jacobian rows of the predicted
+// fields -- J_up (2 x PN) = n s^T with n = (-up_y, up_x), J_lat (1 x PN) = l -- for gclm_jacobian_fields.
+template <int MODEL, bool HAS_UP, bool LOGF, typename F, bool EMIT = false>
 __device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& hk, F xf, float yf, F dux, F duy,
-                                                 F dlat, F cu, F cl, F (&acc)[Layout<MODEL>::NACC]) {
+                                                 F dlat, F cu, F cl, F (&acc)[Layout<MODEL>::NACC],
+                                                 [[maybe_unused]] float* j_up = nullptr,
+                                                 [[maybe_unused]] float* j_lat = nullptr) {
     constexpr bool DIST = MODEL != GCLM_PINHOLE;
     constexpr int ND = Layout<MODEL>::ND, PN = Layout<MODEL>::PN;
     const F u = (xf - P.cx) * P.ifx;
@@ -463,7 +468,17 @@ __device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& 
                 s[3 + j] = vfma(R.ds[j], np_, (R.ds1x2[j] * t) * nuv);
         }
         const F rho = vfma(ux, ry, -(uy * rx));
-        accumulate<MODEL>(acc, s, wgt, rho);
+        if constexpr (EMIT) {
+            if (j_up) {
+#pragma unroll
+                for (int k = 0; k < PN; ++k) {
+                    j_up[k] = -uy * s[k];
+                    j_up[PN + k] = ux * s[k];
+                }
+            }
+        } else {
+            accumulate<MODEL>(acc, s, wgt, rho);
+        }
     }
 
     // The dot-product form of the latitude block is 2-3 % faster for simple_divisional (and the two fast-path
@@ -496,10 +511,17 @@ __device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& 
                 if constexpr (DIST) l[2] = vfma(R.tau, hw, (R.tau1x2 * uvw) * hu);
             }
             if constexpr (DIST) {
-    #pragma unroll
+#pragma unroll
                 for (int j = 0; j < ND; ++j) l[3 + j] = R.dtau[j] * hu;
             }
-            accumulate<MODEL>(acc, l, wgt, rl);
+            if constexpr (EMIT) {
+                if (j_lat) {
+#pragma unroll
+                    for (int k = 0; k < PN; ++k) j_lat[k] = l[k];
+                }
+            } else {
+                accumulate<MODEL>(acc, l, wgt, rl);
+            }
         }
     } else {
         {   // latitude
@@ -538,7 +560,14 @@ __device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& 
                     for (int j = 0; j < ND; ++j) l[3 + j] = R.dtau[j] * hu;
                 }
             }
-            accumulate<MODEL>(acc, l, wgt, rl);
+            if constexpr (EMIT) {
+                if (j_lat) {
+#pragma unroll
+                    for (int k = 0; k < PN; ++k) j_lat[k] = l[k];
+                }
+            } else {
+                accumulate<MODEL>(acc, l, wgt, rl);
+            }
         }
     }
 }
@@ -697,6 +726,40 @@ __global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL >= GCLM_RADIAL) ? 3 : (V
     }
 }
 
+// Per-pixel Jacobian fields of the prediction (perspective_fields.py:323-365), the reference's
+// J_perspective_field as a kernel: one thread per pixel, the parameter block built once per workgroup in LDS.
+// J_up (B,H,W,2,PN), J_lat (B,H,W,1,PN), PN = 3 + #dist.  Not on the solve path (which never materialises these).
+template <int MODEL>
+__global__ __launch_bounds__(kBlock) void jacobian_kernel(const float* cam, const float* grav, int H, int W,
+                                                          int spherical, int log_focal, float* J_up, float* J_lat) {
+    using namespace dev;
+    constexpr int PN = Layout<MODEL>::PN, NACC = Layout<MODEL>::NACC;
+    __shared__ PBlock Ps;
+    const int b = blockIdx.y;
+    if (threadIdx.x == 0) {
+        const float* cm = cam + (size_t)b * GCLM_CAM_STRIDE;
+        State st{};
+        st.w = cm[0]; st.h = cm[1]; st.fx = cm[2]; st.fy = cm[3]; st.cx = cm[4]; st.cy = cm[5]; st.k1 = cm[6]; st.k2 = cm[7];
+        const V3 g = normalize3({grav[b * 3], grav[b * 3 + 1], grav[b * 3 + 2]});
+        st.gx = g.x; st.gy = g.y; st.gz = g.z;
+        PBlock p;
+        build_pblock(st, spherical != 0, log_focal != 0, p);
+        Ps = p;
+    }
+    __syncthreads();
+    const size_t N = (size_t)H * W;
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= N) return;
+    const PBlock P = Ps;
+    const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+    HuberK hk{1.f, 1.f, 1.f, 1.f};
+    float acc[NACC];
+    const size_t px = (size_t)b * N + i;
+    pixel_accumulate<MODEL, true, false, float, true>(P, hk, (float)x, (float)y, 0.f, 0.f, 0.f, 1.f, 1.f, acc,
+                                                      J_up ? J_up + px * 2 * PN : nullptr,
+                                                      J_lat ? J_lat + px * PN : nullptr);
+}
+
 template <int MODEL, int VEC>
 hipError_t dispatch(const SweepArgs& a, hipStream_t s) {
     const dim3 grid(a.nchunks, a.B), block(kBlock);
@@ -734,6 +797,23 @@ hipError_t launch_sweep(int camera_model, const SweepArgs& a, hipStream_t s) {
         case GCLM_SIMPLE_DIVISIONAL: return dispatch_model<GCLM_SIMPLE_DIVISIONAL>(a, s);
         default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_jacobian_fields(int camera_model, const float* d_cam, const float* d_grav, int B, int H, int W,
+                                  int spherical, int log_focal, float* d_J_up, float* d_J_lat, hipStream_t s) {
+    if (B <= 0 || H <= 0 || W <= 0) return hipSuccess;
+    const dim3 grid((unsigned)(((size_t)H * W + kBlock - 1) / kBlock), B), block(kBlock);
+    switch (camera_model) {
+#define GCLM_JAC(M) \
+    case M: hipLaunchKernelGGL(jacobian_kernel<M>, grid, block, 0, s, d_cam, d_grav, H, W, spherical, log_focal, d_J_up, d_J_lat); break
+        GCLM_JAC(GCLM_PINHOLE);
+        GCLM_JAC(GCLM_SIMPLE_RADIAL);
+        GCLM_JAC(GCLM_RADIAL);
+        GCLM_JAC(GCLM_SIMPLE_DIVISIONAL);
+#undef GCLM_JAC
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 }  // namespace gclm

@@ -4,12 +4,16 @@ Forward model of the reference's geocalib/perspective_fields.py (get_up_field :4
 :185, get_perspective_field :278, get_horizon_line :18), written on the radial-model hooks of
 geocalib_amd.camera.  Used to render ground-truth / visualisation fields; the optimiser does NOT
 call this module -- residuals and Jacobians are evaluated per pixel in csrc/gclm_pass.hip.
+
+J_up_field / J_latitude_field / J_perspective_field (:84, :214, :323) return the per-pixel Jacobian fields
+from the same HIP pixel code through gclm_jacobian_fields (device tensors only, no CPU fallback).
 """
 from typing import Tuple
 
 import torch
 from torch.nn import functional as F
 
+from . import _lib
 from .camera import BaseCamera
 from .gravity import Gravity
 
@@ -66,3 +70,49 @@ def get_horizon_line(camera: BaseCamera, gravity: Gravity, relative: bool = True
     t = torch.tan(gravity.roll)
     horizon = camera.new_tensor([mid[1] + mid[0] * t, mid[1] - (camera.size[0] - mid[0]) * t])
     return horizon / camera.size[1] if relative else horizon
+
+
+def _jacobian_fields(camera: BaseCamera, gravity: Gravity, spherical: bool, log_focal: bool, want_up: bool,
+                     want_lat: bool):
+    camera, gravity, h, w = _batched(camera, gravity)
+    cam, grav = camera._data, gravity._data
+    if not (cam.is_cuda and grav.is_cuda):
+        raise RuntimeError("geocalib_amd Jacobian fields need HIP device tensors: they are evaluated by the HIP "
+                           "extension (gclm_jacobian_fields), there is no CPU fallback")
+    lead = cam.shape[:-1]
+    cam = cam.detach().reshape(-1, 8).to(torch.float32).contiguous()
+    grav = grav.detach().reshape(-1, 3).to(torch.float32).contiguous()
+    assert cam.shape[0] == grav.shape[0], (cam.shape, grav.shape)
+    B = cam.shape[0]
+    model = _lib.CAMERA_MODEL_IDS[camera.name()]
+    P = 3 + (camera.num_dist_params() if hasattr(camera, "num_dist_params") else 0)
+    J_up = cam.new_empty((B, h, w, 2, P)) if want_up else None
+    J_lat = cam.new_empty((B, h, w, 1, P)) if want_lat else None
+    ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    with torch.cuda.device(cam.device):
+        rc = _lib.load().gclm_jacobian_fields(model, cam.data_ptr(), grav.data_ptr(), B, h, w, int(spherical),
+                                              int(log_focal), ptr(J_up), ptr(J_lat),
+                                              torch.cuda.current_stream(cam.device).cuda_stream)
+    if rc != 0:
+        raise _lib.GclmError(f"gclm_jacobian_fields failed ({rc})")
+    shape = lambda t: None if t is None else t.reshape(*lead, *t.shape[1:])  # noqa: E731
+    return shape(J_up), shape(J_lat)
+
+
+def J_up_field(camera: BaseCamera, gravity: Gravity, spherical: bool = False, log_focal: bool = False) -> torch.Tensor:
+    """Jacobian of the up field wrt (gravity[2], focal[, dist]): (..., h, w, 2, P)   (perspective_fields.py:84-182)."""
+    return _jacobian_fields(camera, gravity, spherical, log_focal, True, False)[0]
+
+
+def J_latitude_field(camera: BaseCamera, gravity: Gravity, spherical: bool = False,
+                     log_focal: bool = False) -> torch.Tensor:
+    """Jacobian of sin(latitude) wrt (gravity[2], focal[, dist]): (..., h, w, 1, P)   (perspective_fields.py:214-275)."""
+    return _jacobian_fields(camera, gravity, spherical, log_focal, False, True)[1]
+
+
+def J_perspective_field(camera: BaseCamera, gravity: Gravity, use_up: bool = True, use_latitude: bool = True,
+                        spherical: bool = False, log_focal: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(J_up (..., h, w, 2, P), J_lat (..., h, w, 1, P)); a disabled field is zeros (perspective_fields.py:323-365)."""
+    assert use_up or use_latitude, "At least one of use_up or use_latitude must be True."
+    J_up, J_lat = _jacobian_fields(camera, gravity, spherical, log_focal, True, True)
+    return (J_up if use_up else torch.zeros_like(J_up)), (J_lat if use_latitude else torch.zeros_like(J_lat))

@@ -184,6 +184,18 @@ int gclm_pack_fields(const float* d_up_raw, const float* d_up_logconf, const flo
 int gclm_upsample_fields(const float* d_src, int planes, int h, int w, int H, int W, float* d_dst, void* stream);
 
 /*
+ * The reference's J_perspective_field (geocalib/perspective_fields.py:323-365 -> J_up_field :84-182,
+ * J_latitude_field :214-275) as one launch: per-pixel Jacobians of the PREDICTED up / latitude fields of B cameras
+ * wrt (delta_1, delta_2, focal[, k1[, k2]]).  d_cam (B,8), d_grav (B,3) as in gclm_solve; spherical / log_focal
+ * select the tangent basis (SphericalManifold.J_plus vs Gravity.J_rp) and the focal parametrisation exactly as
+ * the reference's flags.  Outputs (either may be NULL): d_J_up (B,H,W,2,P), d_J_lat (B,H,W,1,P) with
+ * P = 3 + number of distortion parameters of `camera_model`.  A solve never materialises these (the sweep
+ * contracts them in registers); this entry point exists for callers and tests that want the fields themselves.
+ */
+int gclm_jacobian_fields(int camera_model, const float* d_cam, const float* d_grav, int B, int H, int W,
+                         int spherical, int log_focal, float* d_J_up, float* d_J_lat, void* stream);
+
+/*
  * Measurement helper (bench.py, tests): synthetic perspective fields generated on the device,
  * SURVEY.md section 8(d).  Image i depends on (seed, first_index + i) only, so every sharding of
  * a batch sees identical data.  Writes the 5 planes and the ground truth (B,8) / (B,3).

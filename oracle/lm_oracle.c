@@ -915,6 +915,29 @@ int lm_oracle_render(int model, int H, int W, const float *cam8, const float *gr
     return 0;
 }
 
+/* Per-pixel Jacobians of the predicted fields wrt (d1, d2, focal[, k1[, k2]]) (perspective_fields.py:323-365:
+ * J_up_field :84-182, J_latitude_field :214-275): J_up (H,W,2,P), J_lat (H,W,1,P), P = 3 + #dist; returns P. */
+int lm_oracle_jacobians(int model, int H, int W, const float *cam8, const float *grav3, int spherical,
+                        int log_focal, double *J_up, double *J_lat) {
+    cam_t c = {cam8[0], cam8[1], cam8[2], cam8[3], cam8[4], cam8[5], cam8[6], cam8[7]};
+    vec3 g = {grav3[0], grav3[1], grav3[2]};
+    real T[3][2];
+    const int P = 3 + num_dist(model);
+    if (spherical) J_plus(g, T); else J_rp(g, T);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            pix_t px;
+            real z2[2] = {0, 0}, z1 = 0;
+            pixel_eval(model, &c, g, T, log_focal, (real)x, (real)y, z2, &z1, 1, &px);
+            for (int k = 0; k < P; ++k) {
+                J_up[((size_t)(y * W + x) * 2 + 0) * P + k] = (double)px.J_up[0][k];
+                J_up[((size_t)(y * W + x) * 2 + 1) * P + k] = (double)px.J_up[1][k];
+                J_lat[(size_t)(y * W + x) * P + k] = (double)px.J_lat[k];
+            }
+        }
+    return P;
+}
+
 /* Single-pass system at given parameters (used by kernel-level parity tests). */
 int lm_oracle_system(const oracle_conf *cf, const oracle_data *d, const float *cam8 /*B x 8*/,
                      const float *grav3 /*B x 3*/, int as_rpf, double *cost_up, double *cost_lat,

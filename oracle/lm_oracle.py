@@ -62,6 +62,7 @@ def _lib(precision: str):
         lib = C.CDLL(path)
         lib.lm_oracle_solve.restype = C.c_int
         lib.lm_oracle_system.restype = C.c_int
+        lib.lm_oracle_jacobians.restype = C.c_int
         _libs[precision] = lib
     return _libs[precision]
 
@@ -145,6 +146,24 @@ def system(data: dict, camera: np.ndarray, gravity: np.ndarray, conf: dict = Non
                              cu.ctypes.data_as(dp), cl.ctypes.data_as(dp), G.ctypes.data_as(dp),
                              Hm.ctypes.data_as(dp))
     return {"cost_up": cu, "cost_lat": cl, "G": G[:, :P].copy(), "H": Hm[:, :P, :P].copy()}
+
+
+def jacobian_fields(camera_model: str, H: int, W: int, camera: np.ndarray, gravity: np.ndarray,
+                    spherical: bool, log_focal: bool, precision: str = "f64"):
+    """Per-pixel Jacobians of the predicted fields (perspective_fields.py:323-365): J_up (B,H,W,2,P),
+    J_lat (B,H,W,1,P) with P = 3 + number of distortion parameters."""
+    lib = _lib(precision)
+    cam, grav = _f32(camera).reshape(-1, 8), _f32(gravity).reshape(-1, 3)
+    B = cam.shape[0]
+    P = 3 + {"pinhole": 0, "simple_radial": 1, "radial": 2, "simple_divisional": 1}[camera_model]
+    J_up = np.zeros((B, H, W, 2, P), np.float64)
+    J_lat = np.zeros((B, H, W, 1, P), np.float64)
+    dp = C.POINTER(C.c_double)
+    for b in range(B):
+        got = lib.lm_oracle_jacobians(CAMERA_MODELS[camera_model], H, W, _ptr(cam[b]), _ptr(grav[b]), int(spherical),
+                                      int(log_focal), J_up[b].ctypes.data_as(dp), J_lat[b].ctypes.data_as(dp))
+        assert got == P
+    return J_up, J_lat
 
 
 def render(camera_model: str, H: int, W: int, camera: np.ndarray, gravity: np.ndarray,

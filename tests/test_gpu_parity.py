@@ -600,3 +600,60 @@ def test_bench_multi_rank_path_on_one_gpu(dev, extra):
     assert out["value"] > 0 and out["unit"] == "images/sec" and out["steps"] == 2
     assert out["check"]["median_focal_rel_err_vs_gt"] < 5e-3
     assert "cpu_baseline" not in out and out["roofline"]["launches_timed"] == 2 * 21
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ALL_MODELS)
+@pytest.mark.parametrize("tag", ["loop", "rpf"])
+def test_jacobian_fields_match_reference(dev, oracle, model, tag):
+    """gclm_jacobian_fields (the sweep's own pixel code writing its rows out) against the reference's
+    J_perspective_field goldens (perspective_fields.py:323-365) and the oracle; host API shapes and flags."""
+    from geocalib_amd import perspective_fields as pf
+    from geocalib_amd.camera import camera_models
+    from geocalib_amd.gravity import Gravity
+    g = np.load(os.path.join(GOLDEN, "golden_jac.npz"))
+    sph = tag == "loop"
+    cam = camera_models[model](torch.from_numpy(g[f"{model}/camera"]).float().to(dev))
+    grav = Gravity(torch.from_numpy(g[f"{model}/gravity"]).float().to(dev))
+    J_up, J_lat = pf.J_perspective_field(cam, grav, spherical=sph, log_focal=sph)
+    ref_up, ref_lat = g[f"{model}/{tag}/J_up"], g[f"{model}/{tag}/J_lat"]
+    assert J_up.shape == ref_up.shape and J_lat.shape == ref_lat.shape
+    tol = 1e-3 if model == "simple_divisional" else 1e-5      # fp32 on |J| <= 2.2; divisional: reference's own cancellation
+    assert np.abs(J_up.cpu().numpy() - ref_up).max() < tol
+    assert np.abs(J_lat.cpu().numpy() - ref_lat).max() < tol
+    o_up, o_lat = oracle.jacobian_fields(model, 12, 16, g[f"{model}/camera"], g[f"{model}/gravity"], sph, sph, precision="f32")
+    assert np.abs(J_up.cpu().numpy() - o_up).max() < tol and np.abs(J_lat.cpu().numpy() - o_lat).max() < tol
+    # single-field entry points, disabled fields, unbatched camera
+    assert torch.equal(pf.J_up_field(cam, grav, sph, sph), J_up) and torch.equal(pf.J_latitude_field(cam, grav, sph, sph), J_lat)
+    z_up, only_lat = pf.J_perspective_field(cam, grav, use_up=False, spherical=sph, log_focal=sph)
+    assert z_up.abs().max() == 0 and torch.equal(only_lat, J_lat)
+    assert torch.equal(pf.J_up_field(cam[0], grav[0], sph, sph), J_up[:1])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pf.J_up_field(cam.cpu(), grav.cpu())
+
+
+@pytest.mark.gpu
+def test_jacobian_fields_contract_to_the_sweep_system(dev):
+    """sum_px w J^T J and w J^T r built from the emitted Jacobian rows reproduce gclm_system's Hessian / gradient
+    (squared loss, unit confidences): the emitted rows ARE what the sweep contracts."""
+    from geocalib_amd import LMOptimizer, perspective_fields as pf
+    from oracle import synth
+    model = "simple_radial"
+    data, cams, gravs = synth.make_fields(11, range(2), model, 40, 52, noise=0.02, confidences=False)
+    opt = LMOptimizer({"camera_model": model, "loss_fn": "squared_loss"}).eval()
+    td = {k: torch.from_numpy(v).to(dev) for k, v in data.items()}
+    cam = opt.camera_model(torch.from_numpy(cams).to(dev))
+    from geocalib_amd.gravity import Gravity
+    grav = Gravity(torch.from_numpy(gravs).to(dev))
+    sysm = opt.system(td, cam, grav)
+    J_up, J_lat = pf.J_perspective_field(cam, grav, spherical=True, log_focal=True)
+    up, lat = pf.get_perspective_field(cam, grav)
+    r_up = (td["up_field"] - up).permute(0, 2, 3, 1).double()                       # (B,H,W,2)
+    r_lat = (torch.sin(td["latitude_field"]) - torch.sin(lat)).permute(0, 2, 3, 1).double()
+    J = torch.cat([J_up, J_lat], -2).double()                                          # (B,H,W,3,P)
+    r = torch.cat([r_up, r_lat], -1)
+    Hs = torch.einsum("bhwrp,bhwrq->bpq", J, J)
+    Gs = torch.einsum("bhwrp,bhwr->bp", J, r)
+    scale = Hs.abs().amax((1, 2), keepdim=True)
+    assert ((Hs - sysm["H"].double()).abs() / scale).max() < 2e-5, ((Hs - sysm["H"]).abs() / scale).max()
+    assert ((Gs - sysm["G"].double()).abs() / Gs.abs().amax(1, keepdim=True)).max() < 2e-4

@@ -134,6 +134,21 @@ def test_oracle_render_matches_reference_fields(oracle):
     assert s["cost_up"].max() < 1e-12 and s["cost_lat"].max() < 1e-12
 
 
+@pytest.mark.parametrize("model", ["pinhole", "simple_radial", "radial", "simple_divisional"])
+@pytest.mark.parametrize("tag", ["loop", "rpf"])
+def test_oracle_jacobian_fields_match_reference(oracle, model, tag):
+    """Per-pixel Jacobians against the reference's J_perspective_field (perspective_fields.py:323-365), both
+    parametrisations (spherical + log focal of the loop, roll/pitch + focal of the uncertainty pass)."""
+    g = np.load(os.path.join(GOLDEN, "golden_jac.npz"))
+    sph = tag == "loop"
+    for prec, tol in (("f64", 1e-6), ("f32", 1e-3 if model == "simple_divisional" else 5e-6)):
+        J_up, J_lat = oracle.jacobian_fields(model, 12, 16, g[f"{model}/camera"], g[f"{model}/gravity"], sph, sph,
+                                             precision=prec)
+        assert J_up.shape == g[f"{model}/{tag}/J_up"].shape and J_lat.shape == g[f"{model}/{tag}/J_lat"].shape
+        assert np.abs(J_up - g[f"{model}/{tag}/J_up"]).max() < tol, (model, tag, prec)
+        assert np.abs(J_lat - g[f"{model}/{tag}/J_lat"]).max() < tol, (model, tag, prec)
+
+
 @pytest.mark.parametrize("model", ["pinhole", "simple_radial"])
 @pytest.mark.parametrize("knob", ["heuristic", "squared_loss"])
 def test_oracle_matches_reference_siclib_knobs(oracle, model, knob):
