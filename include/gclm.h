@@ -12,6 +12,10 @@
  * this boundary.  A handle is not thread-safe: one handle per (device, stream).
  * Numerical failure (non positive-definite system) is NOT an error: the image takes a zero step,
  * like lm_optimizer.py:129-133 (there batch-global, here per image / per shared group).
+ * Degenerate inputs stay contained to their image and never hang (scripts/degenerate_probe.py): an image with
+ * all-zero confidences keeps its initial estimate and reports a non-finite covariance (the reference's
+ * torch.inverse raises on the singular Hessian); a NaN in a field makes THAT image's outputs NaN (its steps count
+ * as failures, the batch-global early stop then never fires) and leaves the other images of the batch untouched.
  */
 #ifndef GCLM_H
 #define GCLM_H
