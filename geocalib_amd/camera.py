@@ -178,6 +178,8 @@ class BaseCamera(TensorWrapper):
                 2 * self._distort_scale_dr2(r2)[..., None] * _outer(p2d, p2d)
         if wrt == "scale2pts":                # ds/dp = 2 s' p
             return 2 * self._distort_scale_dr2(r2) * p2d
+        if wrt == "scale2dist":               # ds/dk_j  (..., N, nd)
+            return self._hook_ddist("_distort_scale", p2d)
         raise NotImplementedError(f"Jacobian not implemented for wrt={wrt}")
 
     def J_undistort(self, p2d: torch.Tensor, wrt: str = "pts") -> torch.Tensor:
@@ -191,6 +193,43 @@ class BaseCamera(TensorWrapper):
     def up_projection_offset(self, p2d: torch.Tensor) -> torch.Tensor:
         """ds/dp of the distortion scale (enters the distorted up field, perspective_fields.py:72)."""
         return self.J_distort(p2d, wrt="scale2pts")
+
+    # Generic derivatives of the radial hooks by autograd (the models with closed forms override the public
+    # methods; the reference's generic versions use torch.func.jacfwd per point, camera.py:216-298).
+    def _per_point(self, p2d: torch.Tensor):
+        """One camera row per point, distortion parameters as a differentiable leaf: (camera, r2, dist)."""
+        n = p2d.shape[-2]
+        data = self._data.reshape(-1, self._data.shape[-1])
+        rows = data[:, None, :].expand(-1, n, -1).reshape(-1, data.shape[-1])
+        nd = self.num_dist_params() if hasattr(self, "num_dist_params") else 0
+        dist = rows[:, 6:6 + nd].detach().clone().requires_grad_(True)
+        cam = self.__class__(torch.cat([rows[:, :6].detach(), dist, rows[:, 6 + nd:].detach()], -1))
+        r2 = (p2d.detach() ** 2).sum(-1).reshape(-1, 1, 1)
+        return cam, r2, dist
+
+    def _hook_dr2(self, hook_name: str, r2: torch.Tensor) -> torch.Tensor:
+        """d hook(r2) / d r2 (elementwise)."""
+        x = r2.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            (g,) = torch.autograd.grad((getattr(self, hook_name)(x) + 0 * x).sum(), x)     # 0*x: constant hooks
+        return g
+
+    def _hook_ddist(self, hook_name: str, p2d: torch.Tensor) -> torch.Tensor:
+        """d hook(|p|^2) / d dist per point: (..., N, num_dist)."""
+        with torch.enable_grad():
+            cam, r2, dist = self._per_point(p2d)
+            (g,) = torch.autograd.grad(getattr(cam, hook_name)(r2).sum() + 0 * dist.sum(), dist)
+        return g.reshape(*p2d.shape[:-1], -1)
+
+    def J_up_projection_offset(self, p2d: torch.Tensor, wrt: str = "uv") -> torch.Tensor:
+        """Jacobian of up_projection_offset(p) = 2 s'(r2) p: wrt "uv" (..., N, 2, 2), wrt "dist" (..., N, 2, nd)."""
+        r2 = (p2d**2).sum(-1, keepdim=True)
+        if wrt == "uv":        # 2 s' I + 4 s'' p p^T
+            s2 = self._hook_dr2("_distort_scale_dr2", r2)
+            return 2 * self._distort_scale_dr2(r2)[..., None] * _eye_like(p2d) + 4 * s2[..., None] * _outer(p2d, p2d)
+        if wrt == "dist":      # 2 p ds'/dk_j
+            return 2 * p2d[..., None] * self._hook_ddist("_distort_scale_dr2", p2d)[..., None, :]
+        raise NotImplementedError(f"Jacobian not implemented for wrt={wrt}")
 
     # ------------------------------------------------------------------ projection chain
     @autocast
