@@ -657,3 +657,41 @@ def test_jacobian_fields_contract_to_the_sweep_system(dev):
     scale = Hs.abs().amax((1, 2), keepdim=True)
     assert ((Hs - sysm["H"].double()).abs() / scale).max() < 2e-5, ((Hs - sysm["H"]).abs() / scale).max()
     assert ((Gs - sysm["G"].double()).abs() / Gs.abs().amax(1, keepdim=True)).max() < 2e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ALL_MODELS)
+def test_jacobian_fields_match_autograd_of_the_forward_model(dev, model):
+    """The reference's own Jacobian test (siclib/geometry/gradient_checker.py: analytic J vs jacfwd, atol 5e-3)
+    restated: gclm_jacobian_fields against torch.func.jacfwd of the float64 host forward model, random cameras in
+    the ranges of TestLM (roll/pitch +-45 deg, vfov 20..90 deg, fx != fy)."""
+    from torch.func import jacfwd
+    from geocalib_amd import perspective_fields as pf
+    from geocalib_amd.camera import camera_models
+    from geocalib_amd.gravity import Gravity
+    H, W = 18, 22
+    nd = 0 if model == "pinhole" else camera_models[model].num_dist_params()
+    rng = np.random.default_rng(77)
+
+    def camera_of(theta):
+        f, k = theta[2], theta[3:3 + nd]
+        kk = torch.cat([k, k]) if nd == 1 else (k if nd == 2 else theta.new_zeros(2))
+        return torch.cat([theta.new_tensor([W, H]), f[None] + 1.5, f[None], theta.new_tensor([W / 2 - 0.7, H / 2 + 0.4]), kk])[None]
+
+    def fwd(theta):
+        cam, grav = camera_models[model](camera_of(theta)), Gravity.from_rp(theta[0][None], theta[1][None])
+        up, lat = pf.get_perspective_field(cam, grav)
+        return torch.cat([up[0].permute(1, 2, 0), torch.sin(lat[0]).permute(1, 2, 0)], -1)     # (H,W,3)
+
+    for _ in range(3):
+        vfov = np.radians(rng.uniform(20, 90))
+        theta = [np.radians(rng.uniform(-45, 45)), np.radians(rng.uniform(-45, 45)), H / 2 / np.tan(vfov / 2)]
+        theta += [rng.uniform(-0.3, 0.1), rng.uniform(-0.03, 0.03)][:nd]
+        theta = torch.tensor(theta, dtype=torch.float64)
+        J_ad = jacfwd(fwd)(theta)                                                                # (H,W,3,P)
+        cam = camera_models[model](camera_of(theta).float().to(dev))
+        grav = Gravity.from_rp(theta[0][None].float().to(dev), theta[1][None].float().to(dev))
+        J_up, J_lat = pf.J_perspective_field(cam, grav, spherical=False, log_focal=False)
+        J = torch.cat([J_up[0], J_lat[0]], -2).double().cpu()
+        tol = 2e-3 if model == "simple_divisional" else 2e-4
+        assert (J - J_ad).abs().max() < tol * max(1.0, J_ad.abs().max().item()), (model, theta, (J - J_ad).abs().max())
