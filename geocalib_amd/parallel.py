@@ -11,6 +11,7 @@ all-reduce(sum) over all groups, then every rank solves the tiny Schur systems r
 updates its own frames.  The reference has no counterpart (its LM is single-process): parity is
 checked on the gathered results against the single-process oracle.
 """
+import os
 from typing import Dict, Tuple
 
 import torch
@@ -33,6 +34,14 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
 
 def pack_rows(cam: torch.Tensor, grav: torch.Tensor, info: torch.Tensor) -> torch.Tensor:
     return torch.cat([cam, grav, info], dim=1).contiguous()
+
+
+def collectives_on(group=None) -> bool:
+    """True when results must go through the collectives: a process group with more than one rank -- or with a
+    single rank and GCLM_FORCE_COLLECTIVES=1, which lets a one-GPU box exercise the RCCL code path end to end."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("GCLM_FORCE_COLLECTIVES") == "1"
 
 
 def unpack_rows(rows: torch.Tensor):
@@ -140,7 +149,7 @@ def calibrate_sharded(opt: LMOptimizer, local_data: Dict[str, torch.Tensor], n_t
     if comm is not None and comm.nranks > 1:       # direct RCCL route (equal shards)
         assert n_total % comm.nranks == 0, "the direct RCCL route expects equal shards"
         return infos_from_rows(opt, comm.all_gather(rows), "up_field" in local_data)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if collectives_on(group):
         rows = all_gather_rows(rows, n_total, group)
         return infos_from_rows(opt, rows, "up_field" in local_data)
     return out
@@ -172,7 +181,7 @@ class SharedIntrinsicsSplit:
             gof = group_of_frame.to(device=dev, dtype=torch.int32).contiguous()
             partials = torch.zeros((self.num_groups, _lib.SHARED_PARTIAL_STRIDE), dtype=torch.float32, device=dev)
             info = torch.empty((B, _lib.INFO_STRIDE), dtype=torch.float32, device=dev)
-            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+            multi = collectives_on(self.group)
             with torch.cuda.device(dev):
                 s = torch.cuda.current_stream(dev).cuda_stream
                 P = opt._ptr

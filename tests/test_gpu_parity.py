@@ -695,3 +695,24 @@ def test_jacobian_fields_match_autograd_of_the_forward_model(dev, model):
         J = torch.cat([J_up[0], J_lat[0]], -2).double().cpu()
         tol = 2e-3 if model == "simple_divisional" else 2e-4
         assert (J - J_ad).abs().max() < tol * max(1.0, J_ad.abs().max().item()), (model, theta, (J - J_ad).abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--shared-group", "16"]])
+def test_bench_collectives_through_rccl_with_one_rank(dev, extra):
+    """The N>1 code path of bench.py with the REAL backend: torch.distributed "nccl" (= RCCL) process group,
+    barrier, max-reduce of the timing, the result all-gather / the per-step all-reduce of the Schur partials --
+    one rank (GCLM_FORCE_COLLECTIVES=1), so it runs on a one-GPU box."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    port = 29900 + (os.getpid() % 90)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--backend", "nccl",
+           "--batch", "64", "--steps", "2", "--warmup", "1", "--cpu-sample", "0"] + extra
+    env = dict(os.environ, GCLM_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["global_batch"] == 64
