@@ -70,6 +70,24 @@ def cpu_baseline(args, n_images):
                       f"(float32, OpenMP over images), {dt:.1f} s"}
 
 
+def ensure_built(local_rank: int) -> None:
+    """The HIP library normally travels with the tree; on a bare checkout local rank 0 builds it (hipcc), the other
+    ranks wait for the file.  There is no fallback: without the library the bench fails."""
+    so = os.path.join(ROOT, "geocalib_amd", "lib", "libgeocalib_hip.so")
+    if os.path.exists(so):
+        return
+    if local_rank == 0:
+        import __graft_entry__
+        __graft_entry__.build()
+        return
+    deadline = time.time() + 900
+    while not os.path.exists(so):
+        if time.time() > deadline:
+            raise SystemExit(f"{so} was not built")
+        time.sleep(1.0)
+    time.sleep(2.0)      # let the linker finish writing
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -91,6 +109,7 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    ensure_built(local_rank)
     from geocalib_amd import LMOptimizer, _lib
     from geocalib_amd.parallel import SharedIntrinsicsSplit, calibrate_sharded
     from geocalib_amd.synth import synth_fields
