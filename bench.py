@@ -77,8 +77,9 @@ def ensure_built(local_rank: int) -> None:
     if os.path.exists(so):
         return
     if local_rank == 0:
-        import __graft_entry__
-        __graft_entry__.build()
+        import subprocess                  # in a child, stdout -> stderr: this process prints ONE JSON line
+        subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT, stdout=sys.stderr,
+                       check=True)
         return
     deadline = time.time() + 900
     while not os.path.exists(so):
