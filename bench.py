@@ -26,6 +26,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required by RCCL across processes here
+os.environ.setdefault("NCCL_DEBUG", "NONE")                # RCCL otherwise prints a 5-line banner on STDOUT; this file prints ONE line
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -712,7 +712,10 @@ def test_bench_collectives_through_rccl_with_one_rank(dev, extra):
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--backend", "nccl",
            "--batch", "64", "--steps", "2", "--warmup", "1", "--cpu-sample", "0"] + extra
     env = dict(os.environ, GCLM_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("NCCL_DEBUG", None)
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert res.returncode == 0, res.stderr[-3000:]
-    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                   # ONE JSON line on stdout, no RCCL banner
+    out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["global_batch"] == 64
