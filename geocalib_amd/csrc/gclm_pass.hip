@@ -74,6 +74,12 @@ __device__ __forceinline__ float vrsq(float a) { return __frsqrt_rn(a); }
 __device__ __forceinline__ f2 vrsq(f2 a) { return f2{__frsqrt_rn(a.x), __frsqrt_rn(a.y)}; }
 __device__ __forceinline__ float vrcp(float a) { return __frcp_rn(a); }
 __device__ __forceinline__ f2 vrcp(f2 a) { return f2{__frcp_rn(a.x), __frcp_rn(a.y)}; }
+// 1-ulp hardware forms (v_rcp_f32 / v_sqrt_f32) for simple_divisional, whose thirteen quotients would otherwise
+// each expand into the ~10-instruction correctly-rounded sequences
+__device__ __forceinline__ float vrcp_hw(float a) { return __builtin_amdgcn_rcpf(a); }
+__device__ __forceinline__ f2 vrcp_hw(f2 a) { return f2{__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}; }
+__device__ __forceinline__ float vsqrt_hw(float a) { return __builtin_amdgcn_sqrtf(a); }
+__device__ __forceinline__ f2 vsqrt_hw(f2 a) { return f2{__builtin_amdgcn_sqrtf(a.x), __builtin_amdgcn_sqrtf(a.y)}; }
 __device__ __forceinline__ float vsqrt(float a) { return __fsqrt_rn(a); }
 __device__ __forceinline__ f2 vsqrt(f2 a) { return f2{__fsqrt_rn(a.x), __fsqrt_rn(a.y)}; }
 __device__ __forceinline__ float vmax(float a, float b) { return fmaxf(a, b); }
@@ -177,42 +183,50 @@ __device__ __forceinline__ void radial_terms(const PBlock& P, F r2, Radial<F>& R
         R.dtau[0] = vfma(r4, vsplat(r2, 6.0f * P.k1), -r2);
         R.dtau[1] = -r4;
     } else if constexpr (MODEL == GCLM_SIMPLE_DIVISIONAL) {      // camera.py:829-940, guards as there
+        // The reference divides by thirteen different products of {r2, t1 = sqrt(max(1 - 4 k r2, 1e-6)), k} and
+        // replaces a denominator that is exactly 0 by 1e6 (masked_fill).  t1 >= 1e-3, so a product vanishes iff
+        // r2 == 0 (indicator r2) or, where k is a factor, r2 k == 0 (indicator rk): every guarded reciprocal is
+        // select(indicator == 0, 1e-6, product of 1/r2, 1/t1, 1/k) -- three reciprocals per pixel instead of
+        // thirteen; the numerators keep the reference's own (cancelling) form.
         const float k = P.k1;
+        const float ik = vrcp_hw(k);                               // inf for k = 0: only read behind the rk selects
         const F tt = vfma(r2, vsplat(r2, -4.0f * k), one);           // 1 - 4 k r2
-        const F den = r2 * (2.0f * k);
-        R.s = vsel_eq0(den, one, (one - vsqrt(vmax(tt, zero))) * vrcp(vguard(den)));
-        const F t0 = vmax(tt, vsplat(r2, 1e-6f));
-        const F t1 = vsqrt(t0), it1 = vrcp(t1);
+        const F rk = r2 * k;
+        const F tiny = vsplat(r2, 1e-6f);
+        const F ssq = vsqrt_hw(vmax(tt, zero));
+        const F t0 = vmax(tt, tiny);
+        const F t1 = vsqrt_hw(t0), it1 = vrcp_hw(t1), it0 = it1 * it1;
+        const F ir2 = vrcp_hw(r2), ir4 = ir2 * ir2, ir6 = ir4 * ir2;    // inf for r2 = 0: only read behind the selects
         const F omt = one - t1;
         const F r4 = r2 * r2;
+        R.s = vsel_eq0(rk, one, (one - ssq) * (ir2 * (0.5f * ik)));   // den = 2 k r2
         {   // J_distort scale2pts (:843-851): off = uv (4 d2 - (1-t1) d1)/(d1 d2), d1 = 2 t1 r2, d2 = k r4
             const F d1 = t1 * (2.0f * r2), d2 = r4 * k;
-            R.s1x2 = vfma(d2, vsplat(r2, 4.0f), -(omt * d1)) * vrcp(vguard(d1 * d2));
+            R.s1x2 = vfma(d2, vsplat(r2, 4.0f), -(omt * d1)) * vsel_eq0(rk, tiny, (ir6 * it1) * (0.5f * ik));
         }
         {   // J_up_projection_offset wrt uv (:912-940): diagonal jd and the uv uv^T coefficient
-            R.jd = 4.0f * vrcp(vguard(2.0f * r2 * t1)) - omt * vrcp(vguard(r4 * k));
-            F pc = -16.0f * vrcp(vguard(4.0f * t1 * r4));
-            pc = pc + (32.0f * k) * vrcp(vguard(4.0f * r2 * t0 * t1));
-            pc = pc - 4.0f * vrcp(vguard(r4 * t1));
-            pc = pc + 4.0f * omt * vrcp(vguard(r4 * r2 * k));
+            const F i_r2t1 = ir2 * it1, i_r4t1 = ir4 * it1;
+            R.jd = 4.0f * vsel_eq0(r2, tiny, 0.5f * i_r2t1) - omt * vsel_eq0(rk, tiny, ir4 * ik);
+            F pc = -16.0f * vsel_eq0(r2, tiny, 0.25f * i_r4t1);
+            pc = pc + (32.0f * k) * vsel_eq0(r2, tiny, 0.25f * (i_r2t1 * it0));
+            pc = pc - 4.0f * vsel_eq0(r2, tiny, i_r4t1);
+            pc = pc + 4.0f * omt * vsel_eq0(rk, tiny, ir6 * ik);
             R.s2x4 = pc;
         }
-        {   // J_distort scale2dist (:853-857)
+        {   // J_distort scale2dist (:853-857): (2 d2 - (1-t1) d1)/(d1 d2), d1 = 2 k t1, d2 = 2 r2 k^2
             const F d1 = t1 * (2.0f * k), d2 = r2 * (2.0f * k * k);
-            R.ds[0] = vfma(d2, vsplat(r2, 2.0f), -(omt * d1)) * vrcp(vguard(d1 * d2));
+            R.ds[0] = vfma(d2, vsplat(r2, 2.0f), -(omt * d1)) * vsel_eq0(rk, tiny, (ir2 * it1) * (0.25f * ik * ik * ik));
         }
-        {   // J_up_projection_offset wrt dist (:898-911)
-            F J = 16.0f * vrcp(vguard(4.0f * t0 * t1));
-            J = J - 2.0f * vrcp(vguard(r2 * t1 * k));
-            const F rk = r2 * k;
-            J = J + omt * vrcp(vguard(rk * rk));
+        {   // J_up_projection_offset wrt dist (:898-911); 4 t0 t1 > 0 needs no guard
+            F J = 4.0f * (it0 * it1);
+            J = J - 2.0f * vsel_eq0(rk, tiny, (ir2 * it1) * ik);
+            J = J + omt * vsel_eq0(rk, tiny, ir4 * (ik * ik));
             R.ds1x2[0] = J;
         }
         const F den2 = vfma(r2, vsplat(r2, k), one);                  // 1 + k r2
-        R.tau = vrcp(vguard(den2));
+        R.tau = vrcp_hw(vguard(den2));
         R.tau1x2 = (-2.0f * k) * R.tau * R.tau;                        // :878-883
-        R.dtau[0] = -r2 * vrcp(vguard(den2 * den2));                   // :875-877
-        (void)it1;
+        R.dtau[0] = -r2 * vsel_eq0(den2, tiny, R.tau * R.tau);         // :875-877
     }
 }
 
