@@ -33,7 +33,7 @@
 // streams a contiguous run of float4 groups of one image with fully coalesced, non-temporal
 // 16 B/lane loads (1 KiB per wave-instruction per plane); the 80-byte parameter block of the image
 // is read with scalar loads (workgroup-uniform -> SGPRs); 16 (24 for `radial`) accumulators per lane
-// are reduced with wave64 shuffles, then across the 4 waves through LDS, and ONE partial record per
+// are reduced per wave with DPP adds (no LDS), then across the 4 waves through LDS, and ONE partial record per
 // workgroup is written (no atomics: bit-reproducible).  No MFMA: the contraction is N x P -> P x P,
 // P <= 5.
 //
@@ -55,6 +55,9 @@
 #endif
 #ifndef GCLM_XCD_REMAP
 #define GCLM_XCD_REMAP 0
+#endif
+#ifndef GCLM_DPP_REDUCE
+#define GCLM_DPP_REDUCE 1
 #endif
 #ifndef GCLM_NT_LOADS
 #define GCLM_NT_LOADS 1
@@ -586,11 +589,34 @@ __device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& 
     }
 }
 
+// wave64 sum.  DPP form (default): four in-row steps (quad_perm x2, row_half_mirror, row_mirror) leave the row sum
+// in every lane of each 16-lane row, row_bcast:15 / row_bcast:31 carry the rows along -- six v_add_f32 with DPP
+// operands, no LDS; the total is valid in lane 63 (kWaveSumLane).  The __shfl_xor butterfly costs six ds_bpermute
+// round trips per value (96 per workgroup epilogue).
+#if GCLM_DPP_REDUCE
+constexpr int kWaveSumLane = 63;
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false);
+    return v + __builtin_bit_cast(float, moved);       // lanes outside ROW_MASK add 0
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = dpp_add<0xB1, 0xF>(v);      // quad_perm:[1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);      // quad_perm:[2,3,0,1]
+    v = dpp_add<0x141, 0xF>(v);     // row_half_mirror
+    v = dpp_add<0x140, 0xF>(v);     // row_mirror
+    v = dpp_add<0x142, 0xA>(v);     // row_bcast:15 -> rows 1, 3
+    v = dpp_add<0x143, 0xC>(v);     // row_bcast:31 -> rows 2, 3
+    return v;
+}
+#else
+constexpr int kWaveSumLane = 0;
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+#endif
 
 // Per-lane tile of one loop iteration: VEC = 4 -> one float4 per plane, processed as two packed
 // pixel pairs; VEC = 1 -> one pixel, scalar math (odd widths / unaligned pointers).
@@ -727,7 +753,7 @@ __global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL >= GCLM_RADIAL) ? 3 : (V
 #pragma unroll
     for (int i = 0; i < NACC; ++i) {
         const float s = wave_sum(hsum(acc[i]));
-        if (lane == 0) red[wave][i] = s;
+        if (lane == kWaveSumLane) red[wave][i] = s;
     }
     __syncthreads();
     if (tid < NACC) {
