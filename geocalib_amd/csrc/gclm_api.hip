@@ -5,6 +5,7 @@
 // (the reference syncs twice per step: H,G -> CPU Cholesky -> device, and torch.allclose).
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -170,6 +171,10 @@ Geometry plan_geometry(int B, int H, int W, bool aligned16) {
     // ~20 loop iterations per thread amortise the 16-value workgroup reduction; fewer when the
     // batch alone cannot fill 256 CUs x 4+ workgroups.
     int iters = 20;
+    if (const char* e = std::getenv("GCLM_SWEEP_ITERS")) {      // tuning experiments only (scripts/README.md)
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 4096) iters = v;
+    }
     auto chunks = [&](int it) { return (g.units + kBlock * it - 1) / (kBlock * it); };
     while (iters > 2 && (long long)B * chunks(iters) < 2048) iters = iters > 5 ? iters / 2 : iters - 1;
     g.units_per_block = kBlock * iters;
