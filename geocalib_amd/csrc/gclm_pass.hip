@@ -750,10 +750,12 @@ __global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL >= GCLM_RADIAL) ? 3 : (V
     // wave64 butterfly, then the 4 waves through LDS; one record per workgroup
     __shared__ float red[kBlock / 64][NACC];
     const int lane = tid & 63, wave = tid >> 6;
+    float wsum[NACC];            // all sums first, ONE predicated store block: the 16 DPP chains interleave
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) {
-        const float s = wave_sum(hsum(acc[i]));
-        if (lane == kWaveSumLane) red[wave][i] = s;
+    for (int i = 0; i < NACC; ++i) wsum[i] = wave_sum(hsum(acc[i]));
+    if (lane == kWaveSumLane) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) red[wave][i] = wsum[i];
     }
     __syncthreads();
     if (tid < NACC) {
