@@ -1,6 +1,6 @@
 // gclm_api.hip -- C ABI of libgeocalib_hip.so (include/gclm.h) and the launch sequence of a solve.
 //
-// A solve is 2*num_steps+4 asynchronous launches on the caller's stream and no host round trip:
+// A solve is 2*num_steps+4 asynchronous launches on the caller's stream and no host round trip (nor memset):
 //   init | { sweep(theta_i) ; update_i } x num_steps | prep_final ; sweep(theta_final, rpf) ; finalize
 // (the reference syncs twice per step: H,G -> CPU Cholesky -> device, and torch.allclose).
 #include <cstdarg>
@@ -282,7 +282,6 @@ static int run_solve(gclm_handle* h, const float* d_up, const float* d_lat, cons
     if (int rc = ensure_workspace(h, B, geo.nchunks, c.n_groups)) return rc;
     h->sh.active = false;
 
-    GCLM_HIP(h, hipMemsetAsync(d_info_out, 0, sizeof(float) * GCLM_INFO_STRIDE * (size_t)B, s));
     GCLM_HIP(h, launch_init(c, ia, s));
     const bool es = h->cfg.early_stop != 0;
     for (int step = 0; step < h->cfg.num_steps; ++step) {
@@ -420,7 +419,6 @@ int gclm_shared_finish(gclm_handle* h, float* d_info_out, void* stream) {
     SolveCtx& c = h->ctx;
     h->sh.active = false;
     if (c.B == 0) return 0;
-    GCLM_HIP(h, hipMemsetAsync(d_info_out, 0, sizeof(float) * GCLM_INFO_STRIDE * (size_t)c.B, s));
     GCLM_HIP(h, launch_prep_final(c, s));
     const SweepArgs a = sweep_args(h, h->sh.up, h->sh.lat, h->sh.upc, h->sh.latc, c.pb_final, h->sh.geo, false, 0);
     if (int rc = timed_sweep(h, a, s)) return rc;

@@ -200,6 +200,13 @@ __global__ __launch_bounds__(kGroups * kSlots) void finalize_kernel(SolveCtx c, 
     if (!c.ctrl->stopped)
         cost_bookkeeping(cfg, c.ctrl, cfg.num_steps, total, s, !cfg.fix_lambda && !cfg.shared_intrinsics);
     float* o = info + (size_t)b * GCLM_INFO_STRIDE;
+    for (int i = 0; i < GCLM_INFO_STRIDE; ++i) o[i] = 0.f;      // every slot is written here: no memset by the caller
+    // stop_at (lm_optimizer.py:575,620,638): first step after which EVERY image's cost was "close"; the counter of
+    // the last comparison (num_steps) cannot change the answer, so nothing of this launch is needed
+    int stop_at = cfg.num_steps;
+    for (int j = 1; j < cfg.num_steps; ++j)
+        if (c.ctrl->notclose[j] == 0) { stop_at = j; break; }
+    o[GCLM_INFO_STOP_AT] = (float)stop_at;
     o[GCLM_INFO_INITIAL_UP_COST] = s.init_cu;
     o[GCLM_INFO_INITIAL_LAT_COST] = s.init_cl;
     o[GCLM_INFO_INITIAL_COST] = s.init_cu + s.init_cl;
@@ -214,7 +221,6 @@ __global__ __launch_bounds__(kGroups * kSlots) void finalize_kernel(SolveCtx c, 
     o[GCLM_INFO_NPARAMS] = (float)n;
     o[GCLM_INFO_LAMBDA] = s.lambda;
     o[GCLM_INFO_STEP_FAILURES] = s.fails;
-    for (int i = GCLM_INFO_ROLL_UNC; i <= GCLM_INFO_VFOV_UNC; ++i) o[i] = 0.f;
     if (cfg.compute_uncertainty) {
         float A[PM][PM], Gf[PM];
         unpack_system<PM>(acc, A, Gf);
@@ -256,16 +262,6 @@ __global__ __launch_bounds__(kGroups * kSlots) void finalize_kernel(SolveCtx c, 
     float* cm = cam + (size_t)b * GCLM_CAM_STRIDE;
     cm[0] = s.w; cm[1] = s.h; cm[2] = s.fx; cm[3] = s.fy; cm[4] = s.cx; cm[5] = s.cy; cm[6] = s.k1; cm[7] = s.k2;
     grav[b * 3] = s.gx; grav[b * 3 + 1] = s.gy; grav[b * 3 + 2] = s.gz;
-}
-
-// stop_at (lm_optimizer.py:575,620,638): first step after which EVERY image's cost was "close".
-__global__ void stop_at_kernel(SolveCtx c, float* info) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= c.B) return;
-    int stop_at = c.cfg.num_steps;
-    for (int j = 1; j <= c.cfg.num_steps; ++j)
-        if (c.ctrl->notclose[j] == 0) { stop_at = j; break; }
-    info[(size_t)b * GCLM_INFO_STRIDE + GCLM_INFO_STOP_AT] = (float)stop_at;
 }
 
 // ---------------------------------------------------------------- shared intrinsics
@@ -630,7 +626,6 @@ hipError_t launch_prep_final(const SolveCtx& c, hipStream_t s) {
 hipError_t launch_finalize(const SolveCtx& c, float* d_cam, float* d_grav, float* d_info, hipStream_t s) {
     if (acc_pm(c.cfg.camera_model) == 5) GCLM_LR(finalize_kernel<5>, c.B, s, c, d_cam, d_grav, d_info);
     else GCLM_LR(finalize_kernel<4>, c.B, s, c, d_cam, d_grav, d_info);
-    GCLM_L(stop_at_kernel, c.B, s, c, d_info);
     return hipGetLastError();
 }
 hipError_t launch_shared_reduce(const SolveCtx& c, int step, float* d_group_partials, hipStream_t s) {
