@@ -426,6 +426,23 @@ int gclm_shared_finish(gclm_handle* h, float* d_info_out, void* stream) {
     return 0;
 }
 
+int gclm_residual_fields(int camera_model, const float* d_up, const float* d_lat, const float* d_cam,
+                         const float* d_grav, int B, int H, int W, float* d_r_up, float* d_r_lat, void* stream) {
+    if (!d_cam || !d_grav || (!d_r_up && !d_r_lat) || B < 0 || H <= 0 || W <= 0) return -3;
+    if ((d_r_up && !d_up) || (d_r_lat && !d_lat)) return -3;
+    if (camera_model < GCLM_PINHOLE || camera_model > GCLM_SIMPLE_DIVISIONAL || B > 65535) return -3;
+    hipError_t e = launch_residual_fields(camera_model, d_up, d_lat, d_cam, d_grav, B, H, W, d_r_up, d_r_lat,
+                                          static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : -10;
+}
+
+int gclm_huber_costs(const float* d_residual, size_t n, int dim, float scale, const float* d_conf, float* d_cost,
+                     float* d_weight, void* stream) {
+    if (!d_residual || (!d_cost && !d_weight) || dim < 1 || dim > 4 || !(scale > 0.f)) return -3;
+    hipError_t e = launch_huber_costs(d_residual, n, dim, scale, d_conf, d_cost, d_weight, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : -10;
+}
+
 int gclm_jacobian_fields(int camera_model, const float* d_cam, const float* d_grav, int B, int H, int W,
                          int spherical, int log_focal, float* d_J_up, float* d_J_lat, void* stream) {
     if (!d_cam || !d_grav || (!d_J_up && !d_J_lat) || B < 0 || H <= 0 || W <= 0) return -3;

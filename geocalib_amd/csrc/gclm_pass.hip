@@ -402,9 +402,10 @@ __device__ __forceinline__ void pixel_accumulate_fast(const PBlock& P, const Hub
     }
 }
 
-// EMIT (scalar instantiation only): instead of accumulating, write the per-pixel Jacobian rows of the predicted
-// fields -- J_up (2 x PN) = n s^T with n = (-up_y, up_x), J_lat (1 x PN) = l -- for gclm_jacobian_fields.
-template <int MODEL, bool HAS_UP, bool LOGF, typename F, bool EMIT = false>
+// EMIT (scalar instantiation only): instead of accumulating, write per-pixel quantities out --
+//   1: the Jacobian rows of the predicted fields, J_up (2 x PN) = n s^T with n = (-up_y, up_x), J_lat (1 x PN) = l
+//      (gclm_jacobian_fields);   2: the residuals r_up (2), r_lat (1) (gclm_residual_fields).
+template <int MODEL, bool HAS_UP, bool LOGF, typename F, int EMIT = 0>
 __device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& hk, F xf, float yf, F dux, F duy,
                                                  F dlat, F cu, F cl, F (&acc)[Layout<MODEL>::NACC],
                                                  [[maybe_unused]] float* j_up = nullptr,
@@ -485,13 +486,18 @@ __device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& 
                 s[3 + j] = vfma(R.ds[j], np_, (R.ds1x2[j] * t) * nuv);
         }
         const F rho = vfma(ux, ry, -(uy * rx));
-        if constexpr (EMIT) {
+        if constexpr (EMIT == 1) {
             if (j_up) {
 #pragma unroll
                 for (int k = 0; k < PN; ++k) {
                     j_up[k] = -uy * s[k];
                     j_up[PN + k] = ux * s[k];
                 }
+            }
+        } else if constexpr (EMIT == 2) {
+            if (j_up) {
+                j_up[0] = rx;
+                j_up[1] = ry;
             }
         } else {
             accumulate<MODEL>(acc, s, wgt, rho);
@@ -531,11 +537,13 @@ __device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& 
 #pragma unroll
                 for (int j = 0; j < ND; ++j) l[3 + j] = R.dtau[j] * hu;
             }
-            if constexpr (EMIT) {
+            if constexpr (EMIT == 1) {
                 if (j_lat) {
 #pragma unroll
                     for (int k = 0; k < PN; ++k) j_lat[k] = l[k];
                 }
+            } else if constexpr (EMIT == 2) {
+                if (j_lat) j_lat[0] = rl;
             } else {
                 accumulate<MODEL>(acc, l, wgt, rl);
             }
@@ -577,11 +585,13 @@ __device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& 
                     for (int j = 0; j < ND; ++j) l[3 + j] = R.dtau[j] * hu;
                 }
             }
-            if constexpr (EMIT) {
+            if constexpr (EMIT == 1) {
                 if (j_lat) {
 #pragma unroll
                     for (int k = 0; k < PN; ++k) j_lat[k] = l[k];
                 }
+            } else if constexpr (EMIT == 2) {
+                if (j_lat) j_lat[0] = rl;
             } else {
                 accumulate<MODEL>(acc, l, wgt, rl);
             }
@@ -797,9 +807,59 @@ __global__ __launch_bounds__(kBlock) void jacobian_kernel(const float* cam, cons
     HuberK hk{1.f, 1.f, 1.f, 1.f};
     float acc[NACC];
     const size_t px = (size_t)b * N + i;
-    pixel_accumulate<MODEL, true, false, float, true>(P, hk, (float)x, (float)y, 0.f, 0.f, 0.f, 1.f, 1.f, acc,
+    pixel_accumulate<MODEL, true, false, float, 1>(P, hk, (float)x, (float)y, 0.f, 0.f, 0.f, 1.f, 1.f, acc,
                                                       J_up ? J_up + px * 2 * PN : nullptr,
                                                       J_lat ? J_lat + px * PN : nullptr);
+}
+
+// Per-pixel residuals (lm_optimizer.py:248-274, calculate_residuals): r_up = up_data - up(theta) (B,N,2),
+// r_lat = sin(lat_data) - sin(lat(theta)) (B,N,1), from the same pixel code.  Not on the solve path.
+template <int MODEL>
+__global__ __launch_bounds__(kBlock) void residual_kernel(const float* up, const float* lat, const float* cam,
+                                                          const float* grav, int H, int W, float* r_up, float* r_lat) {
+    using namespace dev;
+    constexpr int NACC = Layout<MODEL>::NACC;
+    __shared__ PBlock Ps;
+    const int b = blockIdx.y;
+    if (threadIdx.x == 0) {
+        const float* cm = cam + (size_t)b * GCLM_CAM_STRIDE;
+        State st{};
+        st.w = cm[0]; st.h = cm[1]; st.fx = cm[2]; st.fy = cm[3]; st.cx = cm[4]; st.cy = cm[5]; st.k1 = cm[6]; st.k2 = cm[7];
+        const V3 g = normalize3({grav[b * 3], grav[b * 3 + 1], grav[b * 3 + 2]});
+        st.gx = g.x; st.gy = g.y; st.gz = g.z;
+        PBlock p;
+        build_pblock(st, false, false, p);
+        Ps = p;
+    }
+    __syncthreads();
+    const size_t N = (size_t)H * W;
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= N) return;
+    const PBlock P = Ps;
+    const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+    HuberK hk{1.f, 1.f, 1.f, 1.f};
+    float acc[NACC];
+    const size_t px = (size_t)b * N + i;
+    const float dux = up ? up[(size_t)b * 2 * N + i] : 0.f, duy = up ? up[(size_t)b * 2 * N + N + i] : 0.f;
+    const float dl = lat ? lat[px] : 0.f;
+    pixel_accumulate<MODEL, true, false, float, 2>(P, hk, (float)x, (float)y, dux, duy, dl, 1.f, 1.f, acc,
+                                                   r_up ? r_up + px * 2 : nullptr, r_lat ? r_lat + px : nullptr);
+}
+
+// calculate_costs (lm_optimizer.py:276-315) on residual rows of `dim` components: Huber cost and weight of
+// |r|^2 at scale a, both times the confidence -- the sweep's own branch-free form.
+__global__ void huber_costs_kernel(const float* residual, size_t n, int dim, float a, const float* conf, float* cost,
+                                   float* weight) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x2 = 0.f;
+    for (int d = 0; d < dim; ++d) x2 = fmaf(residual[i * dim + d], residual[i * dim + d], x2);
+    const float c = conf ? conf[i] : 1.0f;
+    float acc = 0.f;
+    const float a2 = a * a;
+    const float wc = huber_accumulate(x2, 1.0f / a2, c, acc);
+    if (cost) cost[i] = acc * a2;
+    if (weight) weight[i] = wc;
 }
 
 template <int MODEL, int VEC>
@@ -839,6 +899,31 @@ hipError_t launch_sweep(int camera_model, const SweepArgs& a, hipStream_t s) {
         case GCLM_SIMPLE_DIVISIONAL: return dispatch_model<GCLM_SIMPLE_DIVISIONAL>(a, s);
         default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_residual_fields(int camera_model, const float* d_up, const float* d_lat, const float* d_cam,
+                                  const float* d_grav, int B, int H, int W, float* d_r_up, float* d_r_lat, hipStream_t s) {
+    if (B <= 0 || H <= 0 || W <= 0) return hipSuccess;
+    const dim3 grid((unsigned)(((size_t)H * W + kBlock - 1) / kBlock), B), block(kBlock);
+    switch (camera_model) {
+#define GCLM_RES(M) \
+    case M: hipLaunchKernelGGL(residual_kernel<M>, grid, block, 0, s, d_up, d_lat, d_cam, d_grav, H, W, d_r_up, d_r_lat); break
+        GCLM_RES(GCLM_PINHOLE);
+        GCLM_RES(GCLM_SIMPLE_RADIAL);
+        GCLM_RES(GCLM_RADIAL);
+        GCLM_RES(GCLM_SIMPLE_DIVISIONAL);
+#undef GCLM_RES
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_huber_costs(const float* d_residual, size_t n, int dim, float scale, const float* d_conf,
+                              float* d_cost, float* d_weight, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(huber_costs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_residual, n, dim, scale,
+                       d_conf, d_cost, d_weight);
+    return hipGetLastError();
 }
 
 hipError_t launch_jacobian_fields(int camera_model, const float* d_cam, const float* d_grav, int B, int H, int W,

@@ -309,3 +309,55 @@ class LMOptimizer(nn.Module):
         _lib.check(rc, h.ptr, "gclm_system")
         P = 3 + (self.camera_model.num_dist_params() if self.camera_has_distortion else 0)
         return {"cost_up": cost[:, 0], "cost_lat": cost[:, 1], "G": grad[:, :P], "H": hess[:, :P, :P]}
+
+    # ------------------------------------------------------------------ the reference's per-pixel stages as tensors
+    def calculate_residuals(self, camera: BaseCamera, gravity: Gravity,
+                            data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """`up_residual` (B,N,2) = up_field - prediction, `latitude_residual` (B,N,1) = sin(latitude_field) -
+        sin(prediction), pixels in row-major order (reference: lm_optimizer.py:248-274).  A solve never
+        materialises these; this is the sweep's pixel code writing them out (gclm_residual_fields)."""
+        lat = _dev_f32(data["latitude_field"], "latitude_field") if "latitude_field" in data else None
+        up = _dev_f32(data["up_field"], "up_field") if "up_field" in data else None
+        ref = lat if lat is not None else up
+        assert ref is not None, "data holds neither an up nor a latitude field"
+        B, _, H, W = ref.shape
+        device = ref.device
+        cam = _dev_f32(camera._data, "camera").reshape(-1, 8)
+        grav = _dev_f32(gravity._data, "gravity").reshape(-1, 3)
+        r_up = torch.empty((B, H * W, 2), dtype=torch.float32, device=device) if up is not None else None
+        r_lat = torch.empty((B, H * W, 1), dtype=torch.float32, device=device) if lat is not None else None
+        with torch.cuda.device(device):
+            rc = _lib.load().gclm_residual_fields(_lib.CAMERA_MODEL_IDS[self.camera_model.name()], self._ptr(up),
+                                                  self._ptr(lat), cam.data_ptr(), grav.data_ptr(), B, H, W,
+                                                  self._ptr(r_up), self._ptr(r_lat),
+                                                  torch.cuda.current_stream(device).cuda_stream)
+        if rc != 0:
+            raise _lib.GclmError(f"gclm_residual_fields failed ({rc})")
+        out = {}
+        if r_up is not None:
+            out["up_residual"] = r_up
+        if r_lat is not None:
+            out["latitude_residual"] = r_lat
+        return out
+
+    def calculate_costs(self, residuals: Dict[str, torch.Tensor], data: Dict[str, torch.Tensor]):
+        """(costs, weights): scaled Huber of the squared residual norms, times the confidences when present
+        (reference: lm_optimizer.py:276-315).  Keys `up_cost` / `latitude_cost`, `up_weights` / `latitude_weights`."""
+        costs, weights = {}, {}
+        for key, conf_key, scale, ckey, wkey in (
+                ("up_residual", "up_confidence", self.conf.up_loss_fn_scale, "up_cost", "up_weights"),
+                ("latitude_residual", "latitude_confidence", self.conf.lat_loss_fn_scale, "latitude_cost", "latitude_weights")):
+            if key not in residuals:
+                continue
+            r = _dev_f32(residuals[key], key)
+            B, N, dim = r.shape
+            conf = _dev_f32(data[conf_key], conf_key).reshape(B, N) if conf_key in data else None
+            cost, weight = torch.empty((B, N), dtype=torch.float32, device=r.device), torch.empty((B, N), dtype=torch.float32, device=r.device)
+            scale = self._SQUARED_LOSS_SCALE if self.conf.loss_fn == "squared_loss" else float(scale)
+            with torch.cuda.device(r.device):
+                rc = _lib.load().gclm_huber_costs(r.data_ptr(), B * N, dim, scale, self._ptr(conf), cost.data_ptr(),
+                                                  weight.data_ptr(), torch.cuda.current_stream(r.device).cuda_stream)
+            if rc != 0:
+                raise _lib.GclmError(f"gclm_huber_costs failed ({rc})")
+            costs[ckey], weights[wkey] = cost, weight
+        return costs, weights

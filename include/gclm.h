@@ -188,6 +188,22 @@ int gclm_pack_fields(const float* d_up_raw, const float* d_up_logconf, const flo
 int gclm_upsample_fields(const float* d_src, int planes, int h, int w, int H, int W, float* d_dst, void* stream);
 
 /*
+ * LMOptimizer.calculate_residuals (geocalib/lm_optimizer.py:248-274) as one launch: per-pixel residuals of the
+ * fields against the prediction of (d_cam (B,8), d_grav (B,3)):  d_r_up (B,H*W,2) = up_data - up(theta),
+ * d_r_lat (B,H*W,1) = sin(lat_data) - sin(lat(theta)).  Either output may be NULL (then its field may be NULL).
+ */
+int gclm_residual_fields(int camera_model, const float* d_up, const float* d_lat, const float* d_cam,
+                         const float* d_grav, int B, int H, int W, float* d_r_up, float* d_r_lat, void* stream);
+
+/*
+ * LMOptimizer.calculate_costs (geocalib/lm_optimizer.py:276-315) for one residual tensor: n rows of `dim`
+ * components -> scaled Huber cost and weight of |r|^2 at `scale` (scaled_loss :61-76, huber_loss :79-87), both
+ * multiplied by d_conf (n) when given.  d_cost / d_weight (n) may each be NULL.
+ */
+int gclm_huber_costs(const float* d_residual, size_t n, int dim, float scale, const float* d_conf, float* d_cost,
+                     float* d_weight, void* stream);
+
+/*
  * The reference's J_perspective_field (geocalib/perspective_fields.py:323-365 -> J_up_field :84-182,
  * J_latitude_field :214-275) as one launch: per-pixel Jacobians of the PREDICTED up / latitude fields of B cameras
  * wrt (delta_1, delta_2, focal[, k1[, k2]]).  d_cam (B,8), d_grav (B,3) as in gclm_solve; spherical / log_focal

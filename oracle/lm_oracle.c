@@ -938,6 +938,39 @@ int lm_oracle_jacobians(int model, int H, int W, const float *cam8, const float 
     return P;
 }
 
+/* calculate_residuals (lm_optimizer.py:248-274) of one image: r_up (N,2) = up_data - up(theta), r_lat (N) =
+ * sin(lat_data) - sin(lat(theta)); either field / output pair may be NULL. */
+int lm_oracle_residuals(int model, int H, int W, const float *cam8, const float *grav3, const float *up /*2,H,W*/,
+                        const float *lat /*H,W*/, double *r_up, double *r_lat) {
+    cam_t c = {cam8[0], cam8[1], cam8[2], cam8[3], cam8[4], cam8[5], cam8[6], cam8[7]};
+    vec3 g = {grav3[0], grav3[1], grav3[2]};
+    real T[3][2] = {{0}};
+    const int N = H * W;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const int i = y * W + x;
+            pix_t px;
+            real dup[2] = {0, 0}, dlat = 0;
+            if (up) { dup[0] = up[i]; dup[1] = up[N + i]; }
+            if (lat) dlat = lat[i];
+            pixel_eval(model, &c, g, T, 0, (real)x, (real)y, dup, &dlat, 0, &px);
+            if (up && r_up) { r_up[2 * i] = (double)px.r_up[0]; r_up[2 * i + 1] = (double)px.r_up[1]; }
+            if (lat && r_lat) r_lat[i] = (double)px.r_lat;
+        }
+    return 0;
+}
+
+/* calculate_costs (lm_optimizer.py:276-315) on n squared residual norms: cost and weight, times conf if given. */
+int lm_oracle_huber_costs(const double *x2, int n, double scale, const float *conf, double *cost, double *weight) {
+    for (int i = 0; i < n; ++i) {
+        real w, c = huber((real)x2[i], scale, &w);
+        const real cf = conf ? (real)conf[i] : R(1.0);
+        cost[i] = (double)(c * cf);
+        weight[i] = (double)(w * cf);
+    }
+    return 0;
+}
+
 /* Single-pass system at given parameters (used by kernel-level parity tests). */
 int lm_oracle_system(const oracle_conf *cf, const oracle_data *d, const float *cam8 /*B x 8*/,
                      const float *grav3 /*B x 3*/, int as_rpf, double *cost_up, double *cost_lat,

@@ -166,6 +166,41 @@ def jacobian_fields(camera_model: str, H: int, W: int, camera: np.ndarray, gravi
     return J_up, J_lat
 
 
+def residual_fields(camera_model: str, data: dict, camera: np.ndarray, gravity: np.ndarray, precision: str = "f64"):
+    """calculate_residuals (lm_optimizer.py:248-274): {"up_residual": (B,N,2), "latitude_residual": (B,N,1)}."""
+    lib = _lib(precision)
+    cam, grav = _f32(camera).reshape(-1, 8), _f32(gravity).reshape(-1, 3)
+    up, lat = _f32(data.get("up_field")), _f32(data.get("latitude_field"))
+    ref = lat if lat is not None else up
+    B, _, H, W = ref.shape
+    dp = C.POINTER(C.c_double)
+    r_up = np.zeros((B, H * W, 2), np.float64) if up is not None else None
+    r_lat = np.zeros((B, H * W, 1), np.float64) if lat is not None else None
+    for b in range(B):
+        lib.lm_oracle_residuals(CAMERA_MODELS[camera_model], H, W, _ptr(cam[b]), _ptr(grav[b]),
+                                _ptr(None if up is None else up[b]), _ptr(None if lat is None else lat[b]),
+                                r_up[b].ctypes.data_as(dp) if up is not None else None,
+                                r_lat[b].ctypes.data_as(dp) if lat is not None else None)
+    out = {}
+    if r_up is not None:
+        out["up_residual"] = r_up
+    if r_lat is not None:
+        out["latitude_residual"] = r_lat
+    return out
+
+
+def huber_costs(residual: np.ndarray, scale: float, conf=None, precision: str = "f64"):
+    """calculate_costs (lm_optimizer.py:276-315) of residual rows (..., dim): (cost, weight) of shape (...)."""
+    lib = _lib(precision)
+    x2 = np.ascontiguousarray((np.asarray(residual, np.float64) ** 2).sum(-1))
+    cf = None if conf is None else _f32(conf).reshape(x2.shape)
+    cost, weight = np.zeros_like(x2), np.zeros_like(x2)
+    dp = C.POINTER(C.c_double)
+    lib.lm_oracle_huber_costs(x2.ctypes.data_as(dp), x2.size, C.c_double(scale), _ptr(cf), cost.ctypes.data_as(dp),
+                              weight.ctypes.data_as(dp))
+    return cost, weight
+
+
 def render(camera_model: str, H: int, W: int, camera: np.ndarray, gravity: np.ndarray,
            precision: str = "f64"):
     """Perspective field of each (camera, gravity): up (B,2,H,W), lat (B,1,H,W) (perspective_fields.py:278)."""

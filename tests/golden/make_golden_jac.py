@@ -5,7 +5,8 @@
 The reference's J_perspective_field (perspective_fields.py:323-365 -> J_up_field :84-182, J_latitude_field
 :214-275) for all four camera models, both parametrisations of the LM loop (spherical manifold + log focal)
 and of the uncertainty pass (roll/pitch + plain focal), two cameras each on a 12 x 16 image (float64, so that
-the fixture is the reference's formulas and not their float32 rounding)."""
+the fixture is the reference's formulas and not their float32 rounding); plus calculate_residuals / calculate_costs
+(lm_optimizer.py:248-315, float32) on noisy fields at a perturbed estimate."""
 import os
 import sys
 
@@ -41,6 +42,31 @@ def main():
             out[f"{model}/{tag}/J_up"] = J_up.numpy().copy()
             out[f"{model}/{tag}/J_lat"] = J_lat.numpy().copy()
             print(model, tag, tuple(J_up.shape), tuple(J_lat.shape), float(J_up.abs().max()), float(J_lat.abs().max()))
+    # calculate_residuals / calculate_costs (lm_optimizer.py:248-315) on noisy fields of the same cameras
+    rng = np.random.default_rng(3)
+    for model, cams in CAMS.items():
+        cam = ref.camera.camera_models[model](torch.tensor(cams, dtype=torch.float32))
+        grav = ref.gravity.Gravity.from_rp(torch.tensor([r for r, _ in RP]), torch.tensor([p for _, p in RP]))
+        up, lat = ref.perspective_fields.get_perspective_field(cam, grav)
+        up = torch.nn.functional.normalize(up + torch.from_numpy(rng.normal(0, 0.03, up.shape).astype(np.float32)), dim=1)
+        lat = (lat + torch.from_numpy(rng.normal(0, 0.03, lat.shape).astype(np.float32))).clamp(-1.5, 1.5)
+        data = {"up_field": up, "latitude_field": lat,
+                "up_confidence": torch.from_numpy(rng.uniform(0, 1, (2, H, W)).astype(np.float32)),
+                "latitude_confidence": torch.from_numpy(rng.uniform(0, 1, (2, H, W)).astype(np.float32))}
+        # evaluate at a PERTURBED estimate so that residuals straddle the Huber threshold
+        cam2 = ref.camera.camera_models[model](cam._data * torch.tensor([1, 1, 1.04, 1.04, 1, 1, 0.9, 0.9]))
+        grav2 = ref.gravity.Gravity.from_rp(grav.roll + 0.02, grav.pitch - 0.015)
+        opt = ref.lm_optimizer.LMOptimizer({"camera_model": model})
+        res = opt.calculate_residuals(cam2, grav2, data)
+        costs, weights = opt.calculate_costs(res, data)
+        for k, v in data.items():
+            out[f"{model}/res/{k}"] = v.numpy().copy()
+        out[f"{model}/res/camera"], out[f"{model}/res/gravity"] = cam2._data.numpy().copy(), grav2._data.numpy().copy()
+        for d in (res, costs, weights):
+            for k, v in d.items():
+                out[f"{model}/res/{k}"] = v.numpy().copy()
+        print(model, "residuals", {k: tuple(v.shape) for k, v in res.items()}, "frac beyond Huber threshold",
+              float((weights["up_weights"] < data["up_confidence"].reshape(2, -1) * 0.999).float().mean()))
     np.savez_compressed(os.path.join(HERE, "golden_jac.npz"), **out)
 
 

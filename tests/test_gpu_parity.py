@@ -738,3 +738,38 @@ def test_result_does_not_depend_on_the_chunking(dev, model, monkeypatch):
         assert np.abs(o["gravity"] - outs[0]["gravity"]).max() < 2e-6
         assert np.abs(o["final_cost"] / outs[0]["final_cost"] - 1).max() < 1e-5
         assert np.array_equal(o["stop_at"], outs[0]["stop_at"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ALL_MODELS)
+def test_residuals_and_costs_match_reference(dev, model):
+    """LMOptimizer.calculate_residuals / calculate_costs (gclm_residual_fields, gclm_huber_costs) against the
+    reference's per-pixel outputs (lm_optimizer.py:248-315): noisy fields, perturbed estimate, both Huber branches."""
+    from geocalib_amd import LMOptimizer
+    from geocalib_amd.gravity import Gravity
+    g = np.load(os.path.join(GOLDEN, "golden_jac.npz"))
+    data = {k: torch.from_numpy(g[f"{model}/res/{k}"]).to(dev)
+            for k in ("up_field", "latitude_field", "up_confidence", "latitude_confidence")}
+    opt = LMOptimizer({"camera_model": model}).eval()
+    cam = opt.camera_model(torch.from_numpy(g[f"{model}/res/camera"]).to(dev))
+    grav = Gravity(torch.from_numpy(g[f"{model}/res/gravity"]).to(dev))
+    res = opt.calculate_residuals(cam, grav, data)
+    tol = 2e-5 if model == "simple_divisional" else 2e-6
+    for k in ("up_residual", "latitude_residual"):
+        assert res[k].shape == g[f"{model}/res/{k}"].shape
+        assert np.abs(res[k].cpu().numpy() - g[f"{model}/res/{k}"]).max() < tol, (model, k)
+    costs, weights = opt.calculate_costs({k: torch.from_numpy(g[f"{model}/res/{k}"]).to(dev) for k in res}, data)
+    for ck in ("up_cost", "latitude_cost"):
+        ref = g[f"{model}/res/{ck}"]
+        assert np.abs(costs[ck].cpu().numpy() - ref).max() < 2e-6 * np.abs(ref).max(), (model, ck)
+    for wk in ("up_weights", "latitude_weights"):
+        assert np.abs(weights[wk].cpu().numpy() - g[f"{model}/res/{wk}"]).max() < 2e-6, (model, wk)
+    # missing fields / confidences, and the mean of the per-pixel costs is what the fused sweep reports
+    only_lat = opt.calculate_residuals(cam, grav, {"latitude_field": data["latitude_field"]})
+    assert list(only_lat) == ["latitude_residual"] and torch.equal(only_lat["latitude_residual"], res["latitude_residual"])
+    c2, w2 = opt.calculate_costs(res, {})
+    assert (w2["up_weights"] <= 1).all() and (w2["up_weights"] > 0).all()
+    c3, _ = opt.calculate_costs(res, data)
+    sysm = opt.system(data, cam, grav)
+    assert torch.allclose(c3["up_cost"].mean(1), sysm["cost_up"], rtol=2e-5)
+    assert torch.allclose(c3["latitude_cost"].mean(1), sysm["cost_lat"], rtol=2e-5)

@@ -149,6 +149,23 @@ def test_oracle_jacobian_fields_match_reference(oracle, model, tag):
         assert np.abs(J_lat - g[f"{model}/{tag}/J_lat"]).max() < tol, (model, tag, prec)
 
 
+@pytest.mark.parametrize("model", ["pinhole", "simple_radial", "radial", "simple_divisional"])
+def test_oracle_residuals_and_costs_match_reference(oracle, model):
+    """Per-pixel calculate_residuals / calculate_costs (lm_optimizer.py:248-315) on noisy fields at a perturbed
+    estimate (78 % of the pixels beyond the Huber threshold)."""
+    g = np.load(os.path.join(GOLDEN, "golden_jac.npz"))
+    data = {k: g[f"{model}/res/{k}"] for k in ("up_field", "latitude_field", "up_confidence", "latitude_confidence")}
+    res = oracle.residual_fields(model, data, g[f"{model}/res/camera"], g[f"{model}/res/gravity"], precision="f32")
+    for k in ("up_residual", "latitude_residual"):
+        assert res[k].shape == g[f"{model}/res/{k}"].shape
+        assert np.abs(res[k] - g[f"{model}/res/{k}"]).max() < 1e-6, (model, k)
+    for key, conf, ck, wk in (("up_residual", "up_confidence", "up_cost", "up_weights"),
+                              ("latitude_residual", "latitude_confidence", "latitude_cost", "latitude_weights")):
+        cost, weight = oracle.huber_costs(g[f"{model}/res/{key}"], 1e-2, data[conf], precision="f32")
+        assert np.abs(cost - g[f"{model}/res/{ck}"]).max() < 1e-6 * np.abs(g[f"{model}/res/{ck}"]).max()
+        assert np.abs(weight - g[f"{model}/res/{wk}"]).max() < 1e-6
+
+
 @pytest.mark.parametrize("model", ["pinhole", "simple_radial"])
 @pytest.mark.parametrize("knob", ["heuristic", "squared_loss"])
 def test_oracle_matches_reference_siclib_knobs(oracle, model, knob):
