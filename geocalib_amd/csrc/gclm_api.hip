@@ -426,6 +426,14 @@ int gclm_shared_finish(gclm_handle* h, float* d_info_out, void* stream) {
     return 0;
 }
 
+int gclm_optimizer_step(const float* d_G, const float* d_H, const float* d_lambda, int lambda_is_scalar, float eps,
+                        int B, int P, float* d_delta, int* d_failed, void* stream) {
+    if (!d_G || !d_H || !d_lambda || !d_delta || B < 0 || P < 1 || P > GCLM_MAX_PARAMS) return -3;
+    hipError_t e = launch_lm_step(d_G, d_H, d_lambda, lambda_is_scalar ? 0 : 1, eps, B, P, d_delta, d_failed,
+                                  static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : -10;
+}
+
 int gclm_residual_fields(int camera_model, const float* d_up, const float* d_lat, const float* d_cam,
                          const float* d_grav, int B, int H, int W, float* d_r_up, float* d_r_lat, void* stream) {
     if (!d_cam || !d_grav || (!d_r_up && !d_r_lat) || B < 0 || H <= 0 || W <= 0) return -3;

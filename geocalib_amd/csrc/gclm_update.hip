@@ -601,6 +601,30 @@ __global__ void upsample_bilinear_kernel(const float* __restrict__ src, int plan
     }
 }
 
+// optimizer_step (lm_optimizer.py:109-137) as a batched device kernel: delta = (H + diag(clamp(lambda diag H, eps)))^-1 G
+// by an fp32 Cholesky per system (the reference copies H, G to the CPU for this, twice per LM step).  A system
+// that is not positive definite takes a zero step and raises its flag (the reference zeroes the whole batch).
+template <int N>
+__global__ void lm_step_kernel(const float* G, const float* H, const float* lambda, int lambda_stride, float eps, int B,
+                               float* delta, int* failed) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float A[N][N], g[N];
+    const float lam = lambda[(size_t)b * lambda_stride];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        g[i] = G[(size_t)b * N + i];
+#pragma unroll
+        for (int j = 0; j < N; ++j) A[i][j] = H[((size_t)b * N + i) * N + j];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) A[i][i] += fmaxf(A[i][i] * lam, eps);
+    const bool ok = chol_solve<N>(A, g);
+#pragma unroll
+    for (int i = 0; i < N; ++i) delta[(size_t)b * N + i] = ok ? g[i] : 0.f;
+    if (failed) failed[b] = ok ? 0 : 1;
+}
+
 inline dim3 grid1(int n) { return dim3((n + 127) / 128); }
 
 }  // namespace
@@ -684,6 +708,19 @@ hipError_t launch_synth(int camera_model, uint64_t seed, int64_t first_index, in
     const int bx = (int)((N + 255) / 256 < 64 ? (N + 255) / 256 : 64);
     hipLaunchKernelGGL(synth_kernel, dim3(bx, B), dim3(256), 0, s, camera_model, seed, first_index, B, H, W,
                        sigma, group_size, run, run_stride, up, lat, upc, latc, gt_cam, gt_grav);
+    return hipGetLastError();
+}
+
+hipError_t launch_lm_step(const float* d_G, const float* d_H, const float* d_lambda, int lambda_stride, float eps, int B,
+                          int P, float* d_delta, int* d_failed, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    switch (P) {
+#define GCLM_STEP(N) \
+    case N: hipLaunchKernelGGL(lm_step_kernel<N>, grid1(B), dim3(128), 0, s, d_G, d_H, d_lambda, lambda_stride, eps, B, d_delta, d_failed); break
+        GCLM_STEP(1); GCLM_STEP(2); GCLM_STEP(3); GCLM_STEP(4); GCLM_STEP(5);
+#undef GCLM_STEP
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

@@ -84,6 +84,42 @@ def _dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.detach().to(torch.float32).contiguous()
 
 
+def early_stop(new_cost: torch.Tensor, prev_cost: torch.Tensor, atol: float, rtol: float) -> bool:
+    """Batch-global convergence test of the reference (lm_optimizer.py:90-92).  Inside a solve this decision is
+    taken on the device from per-step counters; the host form is kept for callers that drive their own loop."""
+    return bool(torch.allclose(new_cost, prev_cost, atol=atol, rtol=rtol))
+
+
+def update_lambda(lamb: torch.Tensor, prev_cost: torch.Tensor, new_cost: torch.Tensor, lambda_min: float = 1e-6,
+                  lambda_max: float = 1e2) -> torch.Tensor:
+    """Damping rule (lm_optimizer.py:95-106): x10 where the cost went up, x0.1 elsewhere, clamped."""
+    factor = torch.where(new_cost > prev_cost, torch.full_like(lamb, 10.0), torch.full_like(lamb, 0.1))
+    return (lamb * factor).clamp(lambda_min, lambda_max)
+
+
+def optimizer_step(G: torch.Tensor, H: torch.Tensor, lambda_: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    """One damped Gauss-Newton step per system, delta = (H + diag(clamp(lambda diag H, eps)))^-1 G, solved on the
+    device (gclm_optimizer_step; the reference copies H and G to the CPU, lm_optimizer.py:109-137).  G (..., N),
+    H (..., N, N), lambda_ a scalar tensor or one value per system; N <= 5.  A system that is not positive definite
+    gets a zero step (the reference zeroes the whole batch)."""
+    if not (G.is_cuda and H.is_cuda):
+        raise RuntimeError("geocalib_amd.optimizer_step needs HIP device tensors (no CPU fallback)")
+    N = G.shape[-1]
+    assert H.shape[-2:] == (N, N) and H.shape[:-2] == G.shape[:-1], (G.shape, H.shape)
+    g = G.detach().to(torch.float32).reshape(-1, N).contiguous()
+    h = H.detach().to(torch.float32).reshape(-1, N, N).contiguous()
+    B = g.shape[0]
+    lam = torch.as_tensor(lambda_, dtype=torch.float32, device=g.device).reshape(-1).contiguous()
+    assert lam.numel() in (1, B), f"lambda_ must hold 1 or {B} values"
+    delta = torch.empty_like(g)
+    with torch.cuda.device(g.device):
+        rc = _lib.load().gclm_optimizer_step(g.data_ptr(), h.data_ptr(), lam.data_ptr(), int(lam.numel() == 1), float(eps),
+                                             B, N, delta.data_ptr(), None, torch.cuda.current_stream(g.device).cuda_stream)
+    if rc != 0:
+        raise _lib.GclmError(f"gclm_optimizer_step failed ({rc})")
+    return delta.reshape(G.shape)
+
+
 class LMOptimizer(nn.Module):
     """Batched LM optimiser for camera calibration (HIP / gfx950)."""
 
@@ -361,3 +397,16 @@ class LMOptimizer(nn.Module):
                 raise _lib.GclmError(f"gclm_huber_costs failed ({rc})")
             costs[ckey], weights[wkey] = cost, weight
         return costs, weights
+
+    def update_estimate(self, camera: BaseCamera, gravity: Gravity, delta: torch.Tensor):
+        """Apply one LM step to (camera, gravity) along the columns planned by setup_optimization_and_priors
+        (reference: lm_optimizer.py:518-549).  Inside a solve the per-image kernel does this; the host form composes
+        Gravity.update / update_focal / update_dist for callers that drive their own loop."""
+        zeros = lambda n: delta.new_zeros(delta.shape[:-1] + (n,))  # noqa: E731
+        d_g = delta[..., list(self.gravity_delta_dims)] if self.estimate_gravity else zeros(2)
+        new_gravity = gravity.update(d_g, spherical=self.conf.use_spherical_manifold)
+        d_f = delta[..., list(self.focal_delta_dims)] if self.estimate_focal else zeros(1)
+        new_camera = camera.update_focal(d_f, as_log=self.conf.use_log_focal)
+        if self.camera_has_distortion and self.estimate_dist:
+            new_camera = new_camera.update_dist(delta[..., list(self.dist_delta_dims)])
+        return new_camera, new_gravity

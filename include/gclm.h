@@ -188,6 +188,16 @@ int gclm_pack_fields(const float* d_up_raw, const float* d_up_logconf, const flo
 int gclm_upsample_fields(const float* d_src, int planes, int h, int w, int H, int W, float* d_dst, void* stream);
 
 /*
+ * optimizer_step (geocalib/lm_optimizer.py:109-137) for B systems of P <= 5 unknowns, on the device:
+ *   delta = (H + diag(clamp(lambda * diag(H), min = eps)))^-1 G        (fp32 Cholesky per system)
+ * d_G (B,P), d_H (B,P,P), d_lambda (B) or one value (lambda_is_scalar), d_delta (B,P).  A system that is not
+ * positive definite gets delta = 0 and d_failed[b] = 1 (d_failed may be NULL); the reference moves H and G to the
+ * CPU for this step and zeroes the whole batch on a failure.
+ */
+int gclm_optimizer_step(const float* d_G, const float* d_H, const float* d_lambda, int lambda_is_scalar, float eps,
+                        int B, int P, float* d_delta, int* d_failed, void* stream);
+
+/*
  * LMOptimizer.calculate_residuals (geocalib/lm_optimizer.py:248-274) as one launch: per-pixel residuals of the
  * fields against the prediction of (d_cam (B,8), d_grav (B,3)):  d_r_up (B,H*W,2) = up_data - up(theta),
  * d_r_lat (B,H*W,1) = sin(lat_data) - sin(lat(theta)).  Either output may be NULL (then its field may be NULL).

@@ -773,3 +773,41 @@ def test_residuals_and_costs_match_reference(dev, model):
     sysm = opt.system(data, cam, grav)
     assert torch.allclose(c3["up_cost"].mean(1), sysm["cost_up"], rtol=2e-5)
     assert torch.allclose(c3["latitude_cost"].mean(1), sysm["cost_lat"], rtol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", HIP_MODELS)
+def test_one_lm_step_composed_from_the_public_stages(dev, model):
+    """The reference's loop body written with the public pieces -- system (residuals + costs + Jacobians +
+    reductions), optimizer_step (damped Cholesky on the device), update_estimate -- reproduces what ONE step of the
+    fused solve does; optimizer_step itself is checked against a float64 Cholesky and for its zero-step rule."""
+    from geocalib_amd import LMOptimizer
+    from geocalib_amd.lm_optimizer import early_stop, get_trivial_estimation, optimizer_step, update_lambda
+    data, _, _ = synth_device(model, 4, 96, 128, dev, seed=9)
+    opt = LMOptimizer({"camera_model": model, "num_steps": 1, "early_stop": False}).eval()
+    cam0, grav0 = get_trivial_estimation(data, opt.camera_model)
+    opt.setup_optimization_and_priors(data, shared_intrinsics=False)
+    s = opt.system(data, cam0, grav0)
+    lam = torch.full((4,), 0.1, device=dev)
+    delta = optimizer_step(s["G"], s["H"], lam)
+    cam1, grav1 = opt.update_estimate(cam0, grav0, delta)
+    fused_cam, fused_grav, _ = opt.optimize(data, cam0, grav0)
+    assert torch.allclose(cam1._data, fused_cam._data, rtol=2e-6, atol=1e-6), (cam1._data - fused_cam._data).abs().max()
+    assert torch.allclose(grav1._data, fused_grav._data, atol=1e-6)
+    # against a float64 solve of the damped system
+    H64, G64 = s["H"].double().cpu(), s["G"].double().cpu()
+    A = H64 + torch.diag_embed((H64.diagonal(dim1=-2, dim2=-1) * 0.1).clamp(min=1e-6))
+    ref = torch.cholesky_solve(G64[..., None], torch.linalg.cholesky(A))[..., 0]
+    assert torch.allclose(delta.double().cpu(), ref, rtol=1e-4, atol=1e-7)
+    assert torch.allclose(optimizer_step(s["G"], s["H"], torch.tensor(0.1, device=dev)), delta)      # scalar lambda
+    # a system that is not positive definite takes a zero step and leaves the others alone
+    Hbad = s["H"].clone()
+    Hbad[1] = -Hbad[1]
+    dbad = optimizer_step(s["G"], Hbad, lam)
+    assert dbad[1].abs().max() == 0 and torch.equal(dbad[[0, 2, 3]], delta[[0, 2, 3]])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        optimizer_step(s["G"].cpu(), s["H"].cpu(), lam.cpu())
+    # the two host-side rules of the loop
+    prev, new = torch.tensor([1.0, 2.0, 3.0]), torch.tensor([0.5, 2.5, 3.0])
+    assert torch.allclose(update_lambda(torch.tensor([0.1, 0.1, 50.0]), prev, new), torch.tensor([0.01, 1.0, 5.0]))
+    assert early_stop(prev, prev.clone(), 1e-8, 1e-8) and not early_stop(new, prev, 1e-8, 1e-8)

@@ -196,3 +196,30 @@ def test_trivial_estimation_and_plan():
     assert (cfg.num_steps, cfg.early_stop, cfg.compute_uncertainty, cfg.camera_model) == (20, 0, 1, 0)
     assert LMOptimizer({}).train()._config().compute_uncertainty == 0
     assert LMOptimizer({"camera_model": "radial"})._config().camera_model == 2
+
+
+def test_loop_rules_against_the_reference():
+    """update_lambda / early_stop / update_estimate (host forms) against the reference's (only where it is mounted)."""
+    from oracle import ref_import
+    if not ref_import.available():
+        pytest.skip("reference not mounted")
+    ref = ref_import.load()
+    from geocalib_amd import LMOptimizer, lm_optimizer as lm
+    gen = torch.Generator().manual_seed(8)
+    prev, new, lamb = torch.rand(6, generator=gen), torch.rand(6, generator=gen), torch.rand(6, generator=gen) * 50
+    assert torch.equal(lm.update_lambda(lamb, prev, new), ref.lm_optimizer.update_lambda(lamb, prev, new))
+    for a, b in ((new, prev), (prev, prev + 1e-10)):
+        assert lm.early_stop(a, b, 1e-8, 1e-8) == ref.lm_optimizer.early_stop(a, b, 1e-8, 1e-8)
+    for model in MODELS:
+        cam, grav = make(model, dtype=torch.float32)
+        rc, rg = ref.camera.camera_models[model](cam._data.clone()), ref.gravity.Gravity(grav._data.clone())
+        for data in ({}, {"prior_gravity": 0}, {"prior_focal": 0} if model == "pinhole" else {}):
+            mine, theirs = LMOptimizer({"camera_model": model}), ref.lm_optimizer.LMOptimizer({"camera_model": model})
+            mine.setup_optimization_and_priors(data, shared_intrinsics=False)
+            theirs.setup_optimization_and_priors(data, shared_intrinsics=False)
+            n = 2 * mine.estimate_gravity + mine.estimate_focal + (cam.num_dist_params() if mine.estimate_dist else 0)
+            delta = (torch.rand(3, n, generator=gen) - 0.5) * 0.2
+            c1, g1 = mine.update_estimate(cam, grav, delta)
+            c2, g2 = theirs.update_estimate(rc, rg, delta)
+            assert torch.allclose(c1._data, c2._data, atol=1e-5, rtol=1e-6), (model, data)
+            assert torch.allclose(g1._data, g2._data, atol=1e-6), (model, data)
