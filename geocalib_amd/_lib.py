@@ -60,6 +60,7 @@ _SIGNATURES = {
     "gclm_shared_apply": (C.c_int, [_P, C.c_int, _P, _P]),
     "gclm_shared_finish": (C.c_int, [_P, _P, _P]),
     "gclm_upsample_fields": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "gclm_gradient_hessian": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "gclm_optimizer_step": (C.c_int, [_P, _P, _P, C.c_int, C.c_float, C.c_int, C.c_int, _P, _P, _P]),
     "gclm_residual_fields": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "gclm_huber_costs": (C.c_int, [_P, C.c_size_t, C.c_int, C.c_float, _P, _P, _P, _P]),

@@ -426,6 +426,16 @@ int gclm_shared_finish(gclm_handle* h, float* d_info_out, void* stream) {
     return 0;
 }
 
+int gclm_gradient_hessian(const float* d_J, const float* d_residual, const float* d_weight, int B, int N, int R,
+                          int P, int accumulate, float* d_G, float* d_H, void* stream) {
+    if (!d_J || !d_residual || !d_weight || !d_G || !d_H || B < 0 || N < 0 || R < 1 || R > 4 || P < 1 ||
+        P > GCLM_MAX_PARAMS)
+        return -3;
+    hipError_t e = launch_gradient_hessian(d_J, d_residual, d_weight, B, N, R, P, accumulate, d_G, d_H,
+                                           static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : -10;
+}
+
 int gclm_optimizer_step(const float* d_G, const float* d_H, const float* d_lambda, int lambda_is_scalar, float eps,
                         int B, int P, float* d_delta, int* d_failed, void* stream) {
     if (!d_G || !d_H || !d_lambda || !d_delta || B < 0 || P < 1 || P > GCLM_MAX_PARAMS) return -3;

@@ -89,6 +89,8 @@ struct Geometry {          // how a sweep is cut into blocks
 Geometry plan_geometry(int B, int H, int W, bool aligned16);
 
 // gclm_pass.hip
+hipError_t launch_gradient_hessian(const float* d_J, const float* d_r, const float* d_w, int B, int N, int R, int P,
+                                   int accumulate, float* d_G, float* d_H, hipStream_t s);
 hipError_t launch_lm_step(const float* d_G, const float* d_H, const float* d_lambda, int lambda_stride, float eps, int B,
                           int P, float* d_delta, int* d_failed, hipStream_t s);
 hipError_t launch_residual_fields(int camera_model, const float* d_up, const float* d_lat, const float* d_cam,

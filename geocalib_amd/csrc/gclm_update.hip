@@ -625,6 +625,68 @@ __global__ void lm_step_kernel(const float* G, const float* H, const float* lamb
     if (failed) failed[b] = ok ? 0 : 1;
 }
 
+// calculate_gradient_and_hessian (lm_optimizer.py:317-385) on MATERIALISED tensors: G = sum_px w J^T r,
+// H = sum_px w J^T J for J (B,N,R,P), r (B,N,R), w (B,N).  One workgroup per image, fixed summation order
+// (per-thread strided partial sums in double, then a tree over the 256 threads in LDS).  The solve itself never
+// forms J; this serves callers that hold the tensors.
+template <int P>
+__global__ __launch_bounds__(256) void gradient_hessian_kernel(const float* J, const float* r, const float* w, int N,
+                                                               int R, int accumulate, float* G, float* H) {
+    constexpr int NV = P + P * (P + 1) / 2;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    double acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = 0.0;
+    for (int px = tid; px < N; px += 256) {
+        const size_t q = (size_t)b * N + px;
+        const float wt = w[q];
+        for (int row = 0; row < R; ++row) {
+            const float* j = J + (q * R + row) * P;
+            const float res = r[q * R + row];
+            float jr[P];
+#pragma unroll
+            for (int k = 0; k < P; ++k) jr[k] = j[k];
+            int o = P;
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const float wk = wt * jr[k];
+                acc[k] += (double)(wk * res);
+#pragma unroll
+                for (int l = k; l < P; ++l) acc[o++] += (double)(wk * jr[l]);
+            }
+        }
+    }
+    __shared__ double red[256];
+    double total[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        red[tid] = acc[i];
+        __syncthreads();
+        for (int sft = 128; sft > 0; sft >>= 1) {
+            if (tid < sft) red[tid] += red[tid + sft];
+            __syncthreads();
+        }
+        total[i] = red[0];
+        __syncthreads();
+    }
+    if (tid != 0) return;
+    int o = P;
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        float* g = G + (size_t)b * P + k;
+        *g = (accumulate ? *g : 0.f) + (float)total[k];
+#pragma unroll
+        for (int l = k; l < P; ++l) {
+            const float v = (float)total[o++];
+            float* hkl = H + ((size_t)b * P + k) * P + l;
+            float* hlk = H + ((size_t)b * P + l) * P + k;
+            const float nv = (accumulate ? *hkl : 0.f) + v;
+            *hkl = nv;
+            *hlk = nv;
+        }
+    }
+}
+
 inline dim3 grid1(int n) { return dim3((n + 127) / 128); }
 
 }  // namespace
@@ -719,6 +781,19 @@ hipError_t launch_lm_step(const float* d_G, const float* d_H, const float* d_lam
     case N: hipLaunchKernelGGL(lm_step_kernel<N>, grid1(B), dim3(128), 0, s, d_G, d_H, d_lambda, lambda_stride, eps, B, d_delta, d_failed); break
         GCLM_STEP(1); GCLM_STEP(2); GCLM_STEP(3); GCLM_STEP(4); GCLM_STEP(5);
 #undef GCLM_STEP
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_gradient_hessian(const float* d_J, const float* d_r, const float* d_w, int B, int N, int R, int P,
+                                   int accumulate, float* d_G, float* d_H, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    switch (P) {
+#define GCLM_GH(K) \
+    case K: hipLaunchKernelGGL(gradient_hessian_kernel<K>, dim3(B), dim3(256), 0, s, d_J, d_r, d_w, N, R, accumulate, d_G, d_H); break
+        GCLM_GH(1); GCLM_GH(2); GCLM_GH(3); GCLM_GH(4); GCLM_GH(5);
+#undef GCLM_GH
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

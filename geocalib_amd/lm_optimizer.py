@@ -410,3 +410,85 @@ class LMOptimizer(nn.Module):
         if self.camera_has_distortion and self.estimate_dist:
             new_camera = new_camera.update_dist(delta[..., list(self.dist_delta_dims)])
         return new_camera, new_gravity
+
+    def _column_dims(self):
+        """Columns of the full per-pixel Jacobian [d1, d2, focal, k...] that enter a system (lm_optimizer.py:336-343)."""
+        dims = (0, 1) if self.estimate_gravity else ()
+        if self.estimate_focal:
+            dims += (2,)
+        if self.camera_has_distortion:
+            dims += tuple(range(3, 3 + self.camera_model.num_dist_params()))
+        assert dims, "No parameters to optimize"
+        return list(dims)
+
+    def calculate_gradient_and_hessian(self, J: torch.Tensor, residuals: torch.Tensor, weights: torch.Tensor,
+                                       shared_intrinsics: bool = False):
+        """Grad = sum_px w J^T r (B,P), Hess = sum_px w J^T J (B,P,P) for materialised J (B,N,R,P_full), residuals
+        (B,N,R), weights (B,N) (reference: lm_optimizer.py:317-385; contraction on the device, gclm_gradient_hessian).
+        shared_intrinsics=True returns the reference's arrow-head layout: Grad (1, 2B+ni), Hess (1, 2B+ni, 2B+ni)."""
+        for t in (J, residuals, weights):
+            if not t.is_cuda:
+                raise RuntimeError("calculate_gradient_and_hessian needs HIP device tensors (no CPU fallback)")
+        Jc = J.detach().to(torch.float32)[..., self._column_dims()].contiguous()
+        B, N, R, P = Jc.shape
+        r = residuals.detach().to(torch.float32).reshape(B, N, R).contiguous()
+        w = weights.detach().to(torch.float32).reshape(B, N).contiguous()
+        Grad = torch.empty((B, P), dtype=torch.float32, device=Jc.device)
+        Hess = torch.empty((B, P, P), dtype=torch.float32, device=Jc.device)
+        with torch.cuda.device(Jc.device):
+            rc = _lib.load().gclm_gradient_hessian(Jc.data_ptr(), r.data_ptr(), w.data_ptr(), B, N, R, P, 0, Grad.data_ptr(),
+                                                   Hess.data_ptr(), torch.cuda.current_stream(Jc.device).cuda_stream)
+        if rc != 0:
+            raise _lib.GclmError(f"gclm_gradient_hessian failed ({rc})")
+        if not shared_intrinsics:
+            return Grad, Hess
+        # arrow-head assembly: per-frame gravity blocks on the diagonal, summed intrinsics in the last rows/columns
+        ni = P - 2
+        n = 2 * B + ni
+        G = torch.cat([Grad[:, :2].reshape(-1), Grad[:, 2:].sum(0)])[None]
+        Hs = Hess.new_zeros((n, n))
+        for b in range(B):
+            Hs[2 * b:2 * b + 2, 2 * b:2 * b + 2] = Hess[b, :2, :2]
+        Hs[:2 * B, 2 * B:] = Hess[:, :2, 2:].reshape(2 * B, ni)
+        Hs[2 * B:, :2 * B] = Hess[:, 2:, :2].permute(1, 0, 2).reshape(ni, 2 * B)
+        Hs[2 * B:, 2 * B:] = Hess[:, 2:, 2:].sum(0)
+        return G, Hs[None]
+
+    def setup_system(self, camera: BaseCamera, gravity: Gravity, residuals: Dict[str, torch.Tensor],
+                     weights: Dict[str, torch.Tensor], as_rpf: bool = False, shared_intrinsics: bool = False):
+        """(Grad, Hess) from given per-pixel residuals and weights (reference: lm_optimizer.py:387-461): the Jacobian
+        fields come from gclm_jacobian_fields, the contraction from gclm_gradient_hessian.  The solve uses the fused
+        sweep instead (`system`), which never materialises either."""
+        from .perspective_fields import J_perspective_field
+        J_up, J_lat = J_perspective_field(camera, gravity, spherical=self.conf.use_spherical_manifold and not as_rpf,
+                                          log_focal=self.conf.use_log_focal and not as_rpf)
+        Grad = Hess = None
+        for J, rkey, wkey in ((J_up, "up_residual", "up_weights"), (J_lat, "latitude_residual", "latitude_weights")):
+            if rkey not in residuals:
+                continue
+            Jn = J.reshape(J.shape[0], -1, J.shape[-2], J.shape[-1])
+            g, h = self.calculate_gradient_and_hessian(Jn, residuals[rkey], weights[wkey], shared_intrinsics)
+            Grad, Hess = (g, h) if Grad is None else (Grad + g, Hess + h)
+        assert Grad is not None, "residuals hold neither an up nor a latitude entry"
+        return Grad, Hess
+
+    def estimate_uncertainty(self, camera_opt: BaseCamera, gravity_opt: Gravity, errors: Dict[str, torch.Tensor],
+                             weights: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """Covariance = inverse Hessian in (roll, pitch, focal[, dist]) and the derived standard deviations
+        (reference: lm_optimizer.py:463-516).  `forward` computes the same quantities inside its finalize kernel."""
+        from .misc import J_focal2fov
+        _, Hess = self.setup_system(camera_opt, gravity_opt, errors, weights, as_rpf=True, shared_intrinsics=False)
+        Cov = torch.linalg.inv(Hess)
+        zero = Cov.new_zeros(Cov.shape[:-2])
+        roll = pitch = grav = focal = fov = zero
+        if self.estimate_gravity:
+            roll, pitch = Cov[..., 0, 0], Cov[..., 1, 1]
+            a, b, c = Cov[..., 0, 0], 0.5 * (Cov[..., 0, 1] + Cov[..., 1, 0]), Cov[..., 1, 1]
+            grav = 0.5 * (a + c) + torch.sqrt((0.5 * (a - c)) ** 2 + b ** 2)       # largest eigenvalue of the 2x2 block
+        if self.estimate_focal:
+            i = self.focal_delta_dims[0]
+            focal = Cov[..., i, i]
+            fov = J_focal2fov(camera_opt.f[..., 1], camera_opt.size[..., 1]) ** 2 * focal
+        return {"covariance": Cov, "roll_uncertainty": torch.sqrt(roll), "pitch_uncertainty": torch.sqrt(pitch),
+                "gravity_uncertainty": torch.sqrt(grav), "focal_uncertainty": torch.sqrt(focal) / 2,
+                "vfov_uncertainty": torch.sqrt(fov / 2)}

@@ -188,6 +188,16 @@ int gclm_pack_fields(const float* d_up_raw, const float* d_up_logconf, const flo
 int gclm_upsample_fields(const float* d_src, int planes, int h, int w, int H, int W, float* d_dst, void* stream);
 
 /*
+ * LMOptimizer.calculate_gradient_and_hessian (geocalib/lm_optimizer.py:317-385) on materialised tensors:
+ *   d_G (B,P) = sum_px w J^T r,   d_H (B,P,P) = sum_px w J^T J
+ * for d_J (B,N,R,P), d_residual (B,N,R), d_weight (B,N); R rows per pixel (2 for the up field, 1 for latitude).
+ * `accumulate` != 0 adds to the existing d_G / d_H (up + latitude, :444-459).  The solve itself never forms J
+ * (gclm_solve contracts it in registers); this serves callers that hold the tensors.
+ */
+int gclm_gradient_hessian(const float* d_J, const float* d_residual, const float* d_weight, int B, int N, int R,
+                          int P, int accumulate, float* d_G, float* d_H, void* stream);
+
+/*
  * optimizer_step (geocalib/lm_optimizer.py:109-137) for B systems of P <= 5 unknowns, on the device:
  *   delta = (H + diag(clamp(lambda * diag(H), min = eps)))^-1 G        (fp32 Cholesky per system)
  * d_G (B,P), d_H (B,P,P), d_lambda (B) or one value (lambda_is_scalar), d_delta (B,P).  A system that is not

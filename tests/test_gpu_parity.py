@@ -811,3 +811,39 @@ def test_one_lm_step_composed_from_the_public_stages(dev, model):
     prev, new = torch.tensor([1.0, 2.0, 3.0]), torch.tensor([0.5, 2.5, 3.0])
     assert torch.allclose(update_lambda(torch.tensor([0.1, 0.1, 50.0]), prev, new), torch.tensor([0.01, 1.0, 5.0]))
     assert early_stop(prev, prev.clone(), 1e-8, 1e-8) and not early_stop(new, prev, 1e-8, 1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", HIP_MODELS)
+def test_reference_stage_methods_agree_with_the_fused_path(dev, model):
+    """calculate_residuals -> calculate_costs -> setup_system (materialised Jacobians + device contraction) gives the
+    Hessian / gradient of the fused sweep; estimate_uncertainty on them gives forward's covariance and sigmas; the
+    shared-intrinsics arrow-head has the reference's layout and the fused Schur solve's solution."""
+    from geocalib_amd import LMOptimizer
+    data, _, _ = synth_device(model, 3, 96, 128, dev, seed=21)
+    opt = LMOptimizer({"camera_model": model, "num_steps": 20, "early_stop": False}).eval()
+    out = opt(data)
+    cam, grav = out["camera"], out["gravity"]
+    res = opt.calculate_residuals(cam, grav, data)
+    costs, weights = opt.calculate_costs(res, data)
+    for as_rpf in (False, True):
+        G, H = opt.setup_system(cam, grav, res, weights, as_rpf=as_rpf)
+        s = opt.system(data, cam, grav, as_rpf=as_rpf)
+        scale = s["H"].abs().amax((1, 2), keepdim=True)
+        assert ((H - s["H"]).abs() / scale).max() < 2e-5
+        assert ((G - s["G"]).abs() / s["H"].abs().amax((1, 2)).sqrt()[:, None]).max() < 1e-3     # G ~ 0 at the optimum
+    unc = opt.estimate_uncertainty(cam, grav, res, weights)
+    assert torch.allclose(unc["covariance"], out["covariance"], rtol=2e-3, atol=1e-9)
+    for k in ("roll_uncertainty", "pitch_uncertainty", "gravity_uncertainty", "focal_uncertainty", "vfov_uncertainty"):
+        assert torch.allclose(unc[k], out[k], rtol=2e-3), k
+    # shared intrinsics: dense arrow-head (1, 2B+ni, 2B+ni); its damped solve equals per-frame + shared Schur result
+    cam0, grav0 = cam, grav
+    Gs, Hs = opt.setup_system(cam0, grav0, res, weights, shared_intrinsics=True)
+    ni = opt.n_intrinsic_params
+    assert Gs.shape == (1, 6 + ni) and Hs.shape == (1, 6 + ni, 6 + ni)
+    assert torch.allclose(Hs, Hs.transpose(1, 2))
+    Gf, Hf = opt.setup_system(cam0, grav0, res, weights)
+    assert torch.allclose(Hs[0, 6:, 6:], Hf[:, 2:, 2:].sum(0), rtol=1e-5)
+    assert torch.allclose(Hs[0, 2:4, 2:4], Hf[1, :2, :2]) and torch.allclose(Hs[0, 2:4, 6:], Hf[1, :2, 2:])
+    assert Hs[0, 0:2, 2:4].abs().max() == 0
+    assert torch.allclose(Gs[0, :6].reshape(3, 2), Gf[:, :2]) and torch.allclose(Gs[0, 6:], Gf[:, 2:].sum(0), rtol=1e-5)
