@@ -63,7 +63,7 @@ _SIGNATURES = {
     "gclm_gradient_hessian": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "gclm_optimizer_step": (C.c_int, [_P, _P, _P, C.c_int, C.c_float, C.c_int, C.c_int, _P, _P, _P]),
     "gclm_residual_fields": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
-    "gclm_huber_costs": (C.c_int, [_P, C.c_size_t, C.c_int, C.c_float, _P, _P, _P, _P]),
+    "gclm_huber_costs": (C.c_int, [_P, C.c_size_t, C.c_int, C.c_float, _P, _P, _P, _P, _P]),
     "gclm_jacobian_fields": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "gclm_pack_fields": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "gclm_synth_fields": (C.c_int, [C.c_int, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float,

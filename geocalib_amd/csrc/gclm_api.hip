@@ -455,9 +455,10 @@ int gclm_residual_fields(int camera_model, const float* d_up, const float* d_lat
 }
 
 int gclm_huber_costs(const float* d_residual, size_t n, int dim, float scale, const float* d_conf, float* d_cost,
-                     float* d_weight, void* stream) {
-    if (!d_residual || (!d_cost && !d_weight) || dim < 1 || dim > 4 || !(scale > 0.f)) return -3;
-    hipError_t e = launch_huber_costs(d_residual, n, dim, scale, d_conf, d_cost, d_weight, static_cast<hipStream_t>(stream));
+                     float* d_weight, float* d_second, void* stream) {
+    if (!d_residual || (!d_cost && !d_weight && !d_second) || dim < 0 || dim > 4 || !(scale > 0.f)) return -3;
+    hipError_t e = launch_huber_costs(d_residual, n, dim, scale, d_conf, d_cost, d_weight, d_second,
+                                      static_cast<hipStream_t>(stream));
     return e == hipSuccess ? 0 : -10;
 }
 

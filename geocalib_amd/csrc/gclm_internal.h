@@ -96,7 +96,7 @@ hipError_t launch_lm_step(const float* d_G, const float* d_H, const float* d_lam
 hipError_t launch_residual_fields(int camera_model, const float* d_up, const float* d_lat, const float* d_cam,
                                   const float* d_grav, int B, int H, int W, float* d_r_up, float* d_r_lat, hipStream_t s);
 hipError_t launch_huber_costs(const float* d_residual, size_t n, int dim, float scale, const float* d_conf,
-                              float* d_cost, float* d_weight, hipStream_t s);
+                              float* d_cost, float* d_weight, float* d_second, hipStream_t s);
 hipError_t launch_jacobian_fields(int camera_model, const float* d_cam, const float* d_grav, int B, int H, int W,
                                   int spherical, int log_focal, float* d_J_up, float* d_J_lat, hipStream_t s);
 hipError_t launch_sweep(int camera_model, const SweepArgs& a, hipStream_t s);

@@ -846,13 +846,14 @@ __global__ __launch_bounds__(kBlock) void residual_kernel(const float* up, const
                                                    r_up ? r_up + px * 2 : nullptr, r_lat ? r_lat + px : nullptr);
 }
 
-// calculate_costs (lm_optimizer.py:276-315) on residual rows of `dim` components: Huber cost and weight of
-// |r|^2 at scale a, both times the confidence -- the sweep's own branch-free form.
+// calculate_costs (lm_optimizer.py:276-315) on residual rows of `dim` components (dim = 0: the input already holds
+// |r|^2, as scaled_loss / huber_loss take it): Huber cost and weight at scale a, both times the confidence -- the
+// sweep's own branch-free form -- and optionally the second derivative of the scaled loss (:87, / a^2 of :76).
 __global__ void huber_costs_kernel(const float* residual, size_t n, int dim, float a, const float* conf, float* cost,
-                                   float* weight) {
+                                   float* weight, float* second) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float x2 = 0.f;
+    float x2 = dim == 0 ? residual[i] : 0.f;
     for (int d = 0; d < dim; ++d) x2 = fmaf(residual[i * dim + d], residual[i * dim + d], x2);
     const float c = conf ? conf[i] : 1.0f;
     float acc = 0.f;
@@ -860,6 +861,10 @@ __global__ void huber_costs_kernel(const float* residual, size_t n, int dim, flo
     const float wc = huber_accumulate(x2, 1.0f / a2, c, acc);
     if (cost) cost[i] = acc * a2;
     if (weight) weight[i] = wc;
+    if (second) {
+        const float y = x2 / a2;
+        second[i] = y <= 1.0f ? 0.f : -wc / (2.0f * y * a2);
+    }
 }
 
 template <int MODEL, int VEC>
@@ -919,10 +924,10 @@ hipError_t launch_residual_fields(int camera_model, const float* d_up, const flo
 }
 
 hipError_t launch_huber_costs(const float* d_residual, size_t n, int dim, float scale, const float* d_conf,
-                              float* d_cost, float* d_weight, hipStream_t s) {
+                              float* d_cost, float* d_weight, float* d_second, hipStream_t s) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(huber_costs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_residual, n, dim, scale,
-                       d_conf, d_cost, d_weight);
+                       d_conf, d_cost, d_weight, d_second);
     return hipGetLastError();
 }
 

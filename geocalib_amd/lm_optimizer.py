@@ -84,6 +84,28 @@ def _dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.detach().to(torch.float32).contiguous()
 
 
+def huber_loss(x: torch.Tensor):
+    """Huber loss of an already squared residual `x`: (loss, first derivative = IRLS weight, second derivative)
+    (reference: lm_optimizer.py:79-87), evaluated by gclm_huber_costs in the sweep's branch-free form."""
+    if not x.is_cuda:
+        raise RuntimeError("geocalib_amd.huber_loss needs a HIP device tensor (no CPU fallback)")
+    xs = x.detach().to(torch.float32).contiguous()
+    loss, d1, d2 = torch.empty_like(xs), torch.empty_like(xs), torch.empty_like(xs)
+    with torch.cuda.device(xs.device):
+        rc = _lib.load().gclm_huber_costs(xs.data_ptr(), xs.numel(), 0, 1.0, None, loss.data_ptr(), d1.data_ptr(),
+                                          d2.data_ptr(), torch.cuda.current_stream(xs.device).cuda_stream)
+    if rc != 0:
+        raise _lib.GclmError(f"gclm_huber_costs failed ({rc})")
+    return loss, d1, d2
+
+
+def scaled_loss(x: torch.Tensor, fn, a: float):
+    """`fn` applied to x / a^2, value and derivatives scaled back (reference: lm_optimizer.py:61-76)."""
+    a2 = a**2
+    loss, d1, d2 = fn(x / a2)
+    return loss * a2, d1, d2 / a2
+
+
 def early_stop(new_cost: torch.Tensor, prev_cost: torch.Tensor, atol: float, rtol: float) -> bool:
     """Batch-global convergence test of the reference (lm_optimizer.py:90-92).  Inside a solve this decision is
     taken on the device from per-step counters; the host form is kept for callers that drive their own loop."""
@@ -392,7 +414,7 @@ class LMOptimizer(nn.Module):
             scale = self._SQUARED_LOSS_SCALE if self.conf.loss_fn == "squared_loss" else float(scale)
             with torch.cuda.device(r.device):
                 rc = _lib.load().gclm_huber_costs(r.data_ptr(), B * N, dim, scale, self._ptr(conf), cost.data_ptr(),
-                                                  weight.data_ptr(), torch.cuda.current_stream(r.device).cuda_stream)
+                                                  weight.data_ptr(), None, torch.cuda.current_stream(r.device).cuda_stream)
             if rc != 0:
                 raise _lib.GclmError(f"gclm_huber_costs failed ({rc})")
             costs[ckey], weights[wkey] = cost, weight

@@ -217,11 +217,12 @@ int gclm_residual_fields(int camera_model, const float* d_up, const float* d_lat
 
 /*
  * LMOptimizer.calculate_costs (geocalib/lm_optimizer.py:276-315) for one residual tensor: n rows of `dim`
- * components -> scaled Huber cost and weight of |r|^2 at `scale` (scaled_loss :61-76, huber_loss :79-87), both
- * multiplied by d_conf (n) when given.  d_cost / d_weight (n) may each be NULL.
+ * components (dim = 0: the n inputs already are |r|^2) -> scaled Huber cost and weight at `scale` (scaled_loss
+ * :61-76, huber_loss :79-87), both multiplied by d_conf (n) when given, and the loss's second derivative.
+ * d_cost / d_weight / d_second (n) may each be NULL.
  */
 int gclm_huber_costs(const float* d_residual, size_t n, int dim, float scale, const float* d_conf, float* d_cost,
-                     float* d_weight, void* stream);
+                     float* d_weight, float* d_second, void* stream);
 
 /*
  * The reference's J_perspective_field (geocalib/perspective_fields.py:323-365 -> J_up_field :84-182,

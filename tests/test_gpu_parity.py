@@ -847,3 +847,21 @@ def test_reference_stage_methods_agree_with_the_fused_path(dev, model):
     assert torch.allclose(Hs[0, 2:4, 2:4], Hf[1, :2, :2]) and torch.allclose(Hs[0, 2:4, 6:], Hf[1, :2, 2:])
     assert Hs[0, 0:2, 2:4].abs().max() == 0
     assert torch.allclose(Gs[0, :6].reshape(3, 2), Gf[:, :2]) and torch.allclose(Gs[0, 6:], Gf[:, 2:].sum(0), rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_huber_and_scaled_loss_functions(dev):
+    """huber_loss / scaled_loss (lm_optimizer.py:61-87) against their definition in float64: value, first derivative
+    (the IRLS weight) and second derivative on both sides of the threshold, incl. x = 0."""
+    from geocalib_amd.lm_optimizer import huber_loss, scaled_loss
+    x = torch.cat([torch.zeros(1), torch.logspace(-6, 4, 400)]).to(dev)
+    for a in (1.0, 1e-2):
+        loss, d1, d2 = scaled_loss(x * a * a, huber_loss, a)
+        y = x.double().cpu()
+        sx = torch.sqrt(y + 1e-8)
+        ref_loss = torch.where(y <= 1, y, 2 * sx - 1) * a * a
+        ref_d1 = torch.where(y <= 1, torch.ones_like(y), 1 / sx)
+        ref_d2 = torch.where(y <= 1, torch.zeros_like(y), -(1 / sx) / (2 * y.clamp(min=1e-30))) / (a * a)
+        assert torch.allclose(loss.double().cpu(), ref_loss, rtol=2e-6, atol=1e-12)
+        assert torch.allclose(d1.double().cpu(), ref_d1, rtol=2e-6)
+        assert torch.allclose(d2.double().cpu(), ref_d2, rtol=5e-6, atol=1e-12)
