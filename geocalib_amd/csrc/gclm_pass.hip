@@ -59,6 +59,9 @@
 #ifndef GCLM_DPP_REDUCE
 #define GCLM_DPP_REDUCE 1
 #endif
+#ifndef GCLM_DIV_LITERAL
+#define GCLM_DIV_LITERAL 0
+#endif
 #ifndef GCLM_NT_LOADS
 #define GCLM_NT_LOADS 1
 #endif
@@ -186,6 +189,44 @@ __device__ __forceinline__ void radial_terms(const PBlock& P, F r2, Radial<F>& R
         R.dtau[0] = vfma(r4, vsplat(r2, 6.0f * P.k1), -r2);
         R.dtau[1] = -r4;
     } else if constexpr (MODEL == GCLM_SIMPLE_DIVISIONAL) {      // camera.py:829-940, guards as there
+#if GCLM_DIV_LITERAL      // A/B switch: the reference's thirteen literal quotients (correctly-rounded divisions)
+        const float k = P.k1;
+        const F tt = vfma(r2, vsplat(r2, -4.0f * k), one);           // 1 - 4 k r2
+        const F den = r2 * (2.0f * k);
+        R.s = vsel_eq0(den, one, (one - vsqrt(vmax(tt, zero))) * vrcp(vguard(den)));
+        const F t0 = vmax(tt, vsplat(r2, 1e-6f));
+        const F t1 = vsqrt(t0), it1 = vrcp(t1);
+        const F omt = one - t1;
+        const F r4 = r2 * r2;
+        {   // J_distort scale2pts (:843-851): off = uv (4 d2 - (1-t1) d1)/(d1 d2), d1 = 2 t1 r2, d2 = k r4
+            const F d1 = t1 * (2.0f * r2), d2 = r4 * k;
+            R.s1x2 = vfma(d2, vsplat(r2, 4.0f), -(omt * d1)) * vrcp(vguard(d1 * d2));
+        }
+        {   // J_up_projection_offset wrt uv (:912-940): diagonal jd and the uv uv^T coefficient
+            R.jd = 4.0f * vrcp(vguard(2.0f * r2 * t1)) - omt * vrcp(vguard(r4 * k));
+            F pc = -16.0f * vrcp(vguard(4.0f * t1 * r4));
+            pc = pc + (32.0f * k) * vrcp(vguard(4.0f * r2 * t0 * t1));
+            pc = pc - 4.0f * vrcp(vguard(r4 * t1));
+            pc = pc + 4.0f * omt * vrcp(vguard(r4 * r2 * k));
+            R.s2x4 = pc;
+        }
+        {   // J_distort scale2dist (:853-857)
+            const F d1 = t1 * (2.0f * k), d2 = r2 * (2.0f * k * k);
+            R.ds[0] = vfma(d2, vsplat(r2, 2.0f), -(omt * d1)) * vrcp(vguard(d1 * d2));
+        }
+        {   // J_up_projection_offset wrt dist (:898-911)
+            F J = 16.0f * vrcp(vguard(4.0f * t0 * t1));
+            J = J - 2.0f * vrcp(vguard(r2 * t1 * k));
+            const F rk = r2 * k;
+            J = J + omt * vrcp(vguard(rk * rk));
+            R.ds1x2[0] = J;
+        }
+        const F den2 = vfma(r2, vsplat(r2, k), one);                  // 1 + k r2
+        R.tau = vrcp(vguard(den2));
+        R.tau1x2 = (-2.0f * k) * R.tau * R.tau;                        // :878-883
+        R.dtau[0] = -r2 * vrcp(vguard(den2 * den2));                   // :875-877
+        (void)it1;
+#else
         // The reference divides by thirteen different products of {r2, t1 = sqrt(max(1 - 4 k r2, 1e-6)), k} and
         // replaces a denominator that is exactly 0 by 1e6 (masked_fill).  t1 >= 1e-3, so a product vanishes iff
         // r2 == 0 (indicator r2) or, where k is a factor, r2 k == 0 (indicator rk): every guarded reciprocal is
@@ -230,6 +271,7 @@ __device__ __forceinline__ void radial_terms(const PBlock& P, F r2, Radial<F>& R
         R.tau = vrcp_hw(vguard(den2));
         R.tau1x2 = (-2.0f * k) * R.tau * R.tau;                        // :878-883
         R.dtau[0] = -r2 * vsel_eq0(den2, tiny, R.tau * R.tau);         // :875-877
+#endif
     }
 }
 

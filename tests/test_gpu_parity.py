@@ -439,7 +439,7 @@ def test_randomised_configurations_against_oracle(dev, oracle):
     rng = np.random.default_rng(int(os.environ.get("GCLM_FUZZ_SEED", "2024")))     # soak: GCLM_FUZZ_CASES=400
     worst, undetermined = {}, 0
     for case in range(int(os.environ.get("GCLM_FUZZ_CASES", "40"))):
-        model = ALL_MODELS[rng.integers(0, 3)]                      # simple_divisional has its own loose tests
+        model = ALL_MODELS[rng.integers(0, int(os.environ.get("GCLM_FUZZ_MODELS", "3")))]   # 4: + simple_divisional (soak only)
         H, W = int(rng.integers(24, 90)), int(rng.integers(24, 120))
         if rng.random() < 0.1:                                      # many chunk records per image: striped reduction
             H, W = int(rng.integers(200, 300)), int(rng.integers(260, 340))
@@ -497,7 +497,7 @@ def test_randomised_configurations_against_oracle(dev, oracle):
         worst[case] = spread(out, ref)
         tol = np.array([2e-3, 2e-3, 5e-3, 2e-3]) + 10.0 * own
         assert (worst[case] < tol).all(), (case, model, (H, W), B, conf, worst[case], tol)
-    assert undetermined <= 0.2 * (case + 1), undetermined
+    assert undetermined <= (0.2 if os.environ.get("GCLM_FUZZ_MODELS", "3") == "3" else 0.5) * (case + 1), undetermined
     med = np.median(np.array(list(worst.values())), axis=0)
     assert med[0] < 2e-5 and med[1] < 2e-5 and med[3] < 2e-5, med
 
