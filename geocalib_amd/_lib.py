@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgeocalib_hip.so")
+# GCLM_LIB_PATH: measurement rigs only (same-box A/B of two builds of the library, scripts/ab_lib.sh)
+LIB_PATH = os.environ.get("GCLM_LIB_PATH") or os.path.join(_HERE, "lib", "libgeocalib_hip.so")
 
 CAMERA_MODEL_IDS = {"pinhole": 0, "simple_radial": 1, "radial": 2, "simple_divisional": 3}
 INFO_STRIDE = 48

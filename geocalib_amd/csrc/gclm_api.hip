@@ -115,7 +115,8 @@ SweepArgs sweep_args(const gclm_handle* h, const float* up, const float* lat, co
     a.up = up; a.lat = lat; a.upc = up ? upc : nullptr; a.latc = latc;
     a.pb = pb; a.ctrl = h->ctx.ctrl; a.partials = h->ctx.partials;
     a.B = h->ctx.B; a.H = h->ctx.H; a.W = h->ctx.W;
-    a.nchunks = g.nchunks; a.units_per_block = g.units_per_block; a.vec = g.vec;
+    a.nchunks = g.nchunks; a.vec = g.vec;
+    a.wu = g.wu; a.cu = g.cu; a.nstrips = g.nstrips; a.rpi = g.rpi; a.rows_per_block = g.rows_per_block; a.wpt = g.wpt; a.jobs = g.jobs;
     a.log_focal = loop_params && h->cfg.use_log_focal;   // else the (roll, pitch, focal) block of the final sweep
     a.stop_step = stop_step;
     a.up_scale = h->cfg.up_loss_fn_scale; a.lat_scale = h->cfg.lat_loss_fn_scale;
@@ -163,21 +164,52 @@ int setup_groups(gclm_handle* h, int B) {
 }  // namespace
 
 namespace gclm {
+// Cut one sweep into column-stationary tiles and wave jobs (gclm_pass.hip: sweep_kernel).  A row holds `wu` units
+// (float4 groups, or pixels in the scalar path).  Up to 512 units per row the strip is the whole row and a tile takes
+// `rpi` rows per iteration with rpi * wu lanes rounded up to whole waves -- rpi is chosen for the fewest idle lanes,
+// then for the smallest tile (640 px: 160 units, rpi = 2, 320 lanes = 5 waves, no idle lane).  Wider rows are cut
+// into strips of a multiple of 64 units, one row per iteration.  Every wave of a tile is a job; a workgroup is four
+// consecutive jobs of an image.
 Geometry plan_geometry(int B, int H, int W, bool aligned16) {
     Geometry g;
-    const size_t N = (size_t)H * W;
     g.vec = (aligned16 && (W % 4 == 0)) ? 4 : 1;
-    g.units = (int)(N / g.vec);
-    // ~20 loop iterations per thread amortise the 16-value workgroup reduction; fewer when the
-    // batch alone cannot fill 256 CUs x 4+ workgroups.
+    g.wu = W / g.vec;
+    auto waste = [](int used, int lanes) { return (int)(50.0 * (lanes - used) / lanes); };   // idle lanes, steps of 2 %
+    if (g.wu <= kMaxTile) {
+        g.nstrips = 1;
+        g.cu = g.wu;
+        g.rpi = 1;
+        int best = 1 << 30;
+        for (int r = 1; r * g.wu <= kMaxTile; ++r) {
+            const int lanes = (r * g.wu + 63) / 64 * 64;
+            const int score = waste(r * g.wu, lanes) * 1024 + lanes / 64;
+            if (score < best) { best = score; g.rpi = r; }
+        }
+        g.wpt = (g.rpi * g.wu + 63) / 64;
+    } else {
+        g.rpi = 1;
+        g.cu = 256;
+        int best = 1 << 30;
+        for (int cu = 128; cu <= kMaxTile; cu += 64) {
+            const int ns = (g.wu + cu - 1) / cu;
+            const int score = waste(g.wu, ns * cu) * 1024 + cu / 64;
+            if (score < best) { best = score; g.cu = cu; }
+        }
+        g.nstrips = (g.wu + g.cu - 1) / g.cu;
+        g.wpt = g.cu / 64;
+    }
+    // ~20 loop iterations per lane amortise the 16-value workgroup reduction; fewer when the batch alone cannot
+    // fill 256 CUs x 4+ workgroups.
     int iters = 20;
     if (const char* e = std::getenv("GCLM_SWEEP_ITERS")) {      // tuning experiments only (scripts/README.md)
         const int v = std::atoi(e);
         if (v >= 1 && v <= 4096) iters = v;
     }
-    auto chunks = [&](int it) { return (g.units + kBlock * it - 1) / (kBlock * it); };
+    auto jobs = [&](int it) { return g.nstrips * g.wpt * ((H + g.rpi * it - 1) / (g.rpi * it)); };
+    auto chunks = [&](int it) { return (jobs(it) + kBlock / 64 - 1) / (kBlock / 64); };
     while (iters > 2 && (long long)B * chunks(iters) < 2048) iters = iters > 5 ? iters / 2 : iters - 1;
-    g.units_per_block = kBlock * iters;
+    g.rows_per_block = g.rpi * iters;
+    g.jobs = jobs(iters);
     g.nchunks = chunks(iters);
     return g;
 }

@@ -9,7 +9,8 @@
 
 namespace gclm {
 
-constexpr int kBlock = 256;        // 4 waves of 64
+constexpr int kBlock = 256;        // 4 waves of 64 (per-pixel helper kernels)
+constexpr int kMaxTile = 512;      // most lanes of one column-stationary tile of the sweep (see plan_geometry)
 constexpr int kNAcc = 16;          // floats per partial record for models with <= 4 parameters (see enum Acc)
 constexpr int kNAccMax = 24;       // ... and for the 5-parameter `radial` model (2 + 5 + 15 = 22, padded)
 constexpr int kPBlockFloats = 20;
@@ -75,16 +76,19 @@ struct SweepArgs {
     const Ctrl* ctrl;       // nullptr: never skip
     float* partials;        // (B, nchunks, acc_floats(model))
     int B, H, W;
-    int nchunks;            // blocks per image
-    int units_per_block;    // float4 groups (or pixels in the scalar path) per block
+    int nchunks;            // workgroups (partial records) per image = ceil(jobs / 4)
     int vec;                // 4: float4 path, 1: scalar path
+    int wu, cu, nstrips;    // units (float4 groups / pixels) per row, per strip, strips per row
+    int rpi, rows_per_block;// rows per loop iteration of a tile (tile lanes / cu), rows a tile walks down
+    int wpt, jobs;          // waves per tile (rpi * cu lanes rounded up to whole waves), wave jobs per image
     int log_focal;          // the parameter block was built for the log-focal parametrisation (wfx = wfy = 1)
     int stop_step;          // >= 2: LM step of this loop sweep, skipped once the early stop has fired (else 0)
     float up_scale, lat_scale;   // Huber scales a (lm_optimizer.py:158-159)
 };
 
-struct Geometry {          // how a sweep is cut into blocks
-    int vec, units, nchunks, units_per_block;
+struct Geometry {          // how a sweep is cut into blocks (column-stationary tiles, see gclm_pass.hip)
+    int vec, nchunks;
+    int wu, cu, nstrips, rpi, rows_per_block, wpt, jobs;
 };
 Geometry plan_geometry(int B, int H, int W, bool aligned16);
 

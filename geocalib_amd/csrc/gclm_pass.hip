@@ -305,11 +305,11 @@ __device__ __forceinline__ void accumulate(F (&acc)[Layout<MODEL>::NACC], const 
 // n.w = -n.uv, m.w = -m.uv, uv.w = -r2, p.w = -t, h.w = -h.uv, and the focal column collapses to
 //   up:  s2 = c (m.uv) - 2 k1 s3          lat:  l2 = -e (h.uv) - 2 k1 l3
 template <int MODEL, bool HAS_UP, bool LOGF, typename F>
-__device__ __forceinline__ void pixel_accumulate_fast(const PBlock& P, const HuberK& hk, F xf, float yf, F dux, F duy,
+__device__ __forceinline__ void pixel_accumulate_fast(const PBlock& P, const HuberK& hk, F u, F px, float v, F dux, F duy,
                                                  F dlat, F cu, F cl, F (&acc)[kNAcc]) {
     constexpr bool DIST = MODEL != GCLM_PINHOLE;
-    const F u = (xf - P.cx) * P.ifx;
-    const float v = (yf - P.cy) * P.ify;                 // one image row per tile: v is lane-scalar
+    // u = (x - cx)/fx and px = ga - gc u belong to the lane's COLUMN and are loop invariants of the sweep
+    // (column-stationary mapping, see sweep_kernel); v = (y - cy)/fy is lane-scalar (one image row per tile)
     const F r2 = vfma(u, u, vsplat(u, v * v));
     [[maybe_unused]] F wx = vsplat(u, 0.f), uvw = vsplat(u, 0.f);
     [[maybe_unused]] float wy = 0.f;
@@ -321,7 +321,6 @@ __device__ __forceinline__ void pixel_accumulate_fast(const PBlock& P, const Hub
     const float k1x2 = 2.0f * P.k1;
 
     if constexpr (HAS_UP) {
-        const F px = vfma(u, vsplat(u, -P.gc), vsplat(u, P.ga));
         const float py = fmaf(-P.gc, v, P.gb);
         F qx = px, qy = vsplat(u, py), d = vsplat(u, 1.0f), t = vsplat(u, 0.f);
         if constexpr (DIST) {
@@ -448,14 +447,12 @@ __device__ __forceinline__ void pixel_accumulate_fast(const PBlock& P, const Hub
 //   1: the Jacobian rows of the predicted fields, J_up (2 x PN) = n s^T with n = (-up_y, up_x), J_lat (1 x PN) = l
 //      (gclm_jacobian_fields);   2: the residuals r_up (2), r_lat (1) (gclm_residual_fields).
 template <int MODEL, bool HAS_UP, bool LOGF, typename F, int EMIT = 0>
-__device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& hk, F xf, float yf, F dux, F duy,
+__device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& hk, F u, F px, float v, F dux, F duy,
                                                  F dlat, F cu, F cl, F (&acc)[Layout<MODEL>::NACC],
                                                  [[maybe_unused]] float* j_up = nullptr,
                                                  [[maybe_unused]] float* j_lat = nullptr) {
     constexpr bool DIST = MODEL != GCLM_PINHOLE;
     constexpr int ND = Layout<MODEL>::ND, PN = Layout<MODEL>::PN;
-    const F u = (xf - P.cx) * P.ifx;
-    const float v = (yf - P.cy) * P.ify;                 // one image row per tile: v is lane-scalar
     const F r2 = vfma(u, u, vsplat(u, v * v));
     [[maybe_unused]] F wx = vsplat(u, 0.f), uvw = vsplat(u, 0.f);
     [[maybe_unused]] float wy = 0.f;
@@ -468,7 +465,6 @@ __device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& 
     radial_terms<MODEL>(P, r2, R);
 
     if constexpr (HAS_UP) {
-        const F px = vfma(u, vsplat(u, -P.gc), vsplat(u, P.ga));
         const float py = fmaf(-P.gc, v, P.gb);
         F qx = px, qy = vsplat(u, py), t = vsplat(u, 0.f);
         if constexpr (DIST) {
@@ -672,6 +668,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // Per-lane tile of one loop iteration: VEC = 4 -> one float4 per plane, processed as two packed
 // pixel pairs; VEC = 1 -> one pixel, scalar math (odd widths / unaligned pointers).
+// Loads are "uniform base pointer + 32-bit per-lane byte offset" (global_load ... v_off, s[base:base+1]): one
+// v_add_u32 per iteration advances all five planes (per-plane 64-bit pointers cost five v_lshl_add_u64).
 template <int VEC>
 struct Lane;
 template <>
@@ -679,15 +677,16 @@ struct Lane<4> {
     using F = f2;
     using V = float4;
     static constexpr int kPairs = 2;
-    static __device__ __forceinline__ V ld(const float* p, size_t unit) {
+    static __device__ __forceinline__ V ld(const float* base, uint32_t byte_off) {
+        typedef float v4 __attribute__((ext_vector_type(4)));
+        const v4* p = reinterpret_cast<const v4*>(reinterpret_cast<const char*>(base) + byte_off);
 #if GCLM_NT_LOADS
         // every byte is read exactly once per sweep: stream it past the caches (global_load ... nt)
-        typedef float v4 __attribute__((ext_vector_type(4)));
-        const v4 t = __builtin_nontemporal_load(reinterpret_cast<const v4*>(p + unit * 4));
-        return make_float4(t.x, t.y, t.z, t.w);
+        const v4 t = __builtin_nontemporal_load(p);
 #else
-        return *reinterpret_cast<const float4*>(p + unit * 4);
+        const v4 t = *p;
 #endif
+        return make_float4(t.x, t.y, t.z, t.w);
     }
     static __device__ __forceinline__ F get(const V& v, int k) { return k == 0 ? f2{v.x, v.y} : f2{v.z, v.w}; }
     static __device__ __forceinline__ V ones() { return make_float4(1.f, 1.f, 1.f, 1.f); }
@@ -701,12 +700,24 @@ struct Lane<1> {
     using F = float;
     using V = float;
     static constexpr int kPairs = 1;
-    static __device__ __forceinline__ V ld(const float* p, size_t unit) { return p[unit]; }
+    static __device__ __forceinline__ V ld(const float* base, uint32_t byte_off) {
+        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+    }
     static __device__ __forceinline__ F get(const V& v, int) { return v; }
     static __device__ __forceinline__ V ones() { return 1.f; }
     static __device__ __forceinline__ F xcoord(int x, int) { return (float)x; }
 };
 
+// COLUMN-STATIONARY mapping.  The unit of work is a WAVE JOB: 64 consecutive lanes of a tile of `rpi` rows x `cu`
+// units (float4 groups, or pixels in the scalar path) of ONE image, walking down `rows_per_block` rows, `rpi` rows
+// per iteration; lane f of the tile sits at (row f / cu, unit f % cu) and NEVER changes its column.  With a single
+// strip (cu = units per row: every width up to 2048 px) a tile is rpi whole rows = one contiguous run of memory, so
+// a wave still reads 1 KiB of consecutive addresses per plane and instruction (640 px: 160 units per row, 2 rows
+// = 320 lanes = 5 waves per tile).  A 256-thread workgroup takes four consecutive jobs of an image, whatever
+// tiles they belong to, and writes one partial record.  What it buys: everything that depends on the column
+// only -- u = (x - cx)/fx, p_x = ga - gc u, the int -> float conversions behind them -- leaves the loop, the byte
+// offset advances by a wave-uniform constant, and the loop bookkeeping is one add and one compare (the row-major
+// streaming it replaced spent ~21 of 295 VALU instructions per 4 pixels on these; scripts/isa_stats.py).
 template <int MODEL, bool HAS_UP, bool HAS_UPC, bool HAS_LATC, bool LOGF, int VEC>
 // launch bounds: radial / simple_divisional are held to 168 VGPRs (3 waves per SIMD); the two BASELINE models
 // reach 96 / 128 on their own
@@ -736,9 +747,6 @@ __global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL >= GCLM_RADIAL) ? 3 : (V
     hk.inv_a2l = 1.0f / hk.a2l;
 
     const size_t N = (size_t)a.H * a.W;
-    const int units = (int)(N / VEC);
-    const int u0 = chunk * a.units_per_block;
-    const int u1 = min(u0 + a.units_per_block, units);
     const float* upx = HAS_UP ? a.up + (size_t)b * 2 * N : nullptr;
     const float* upy = HAS_UP ? upx + N : nullptr;
     const float* lat = a.lat + (size_t)b * N;
@@ -752,56 +760,63 @@ __global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL >= GCLM_RADIAL) ? 3 : (V
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = F(0.f);
 
-    int unit = u0 + tid;
-    int pix = unit * VEC;
-    int y = pix / a.W;
-    int x = pix - y * a.W;
-    const int step_pix = kBlock * VEC;
-    const int dy = step_pix / a.W, dx = step_pix - dy * a.W;
-    for (; unit < u1; unit += kBlock) {
-        V vux, vuy, vcu = L::ones(), vcl = L::ones();
-        if constexpr (HAS_UP) {
-            vux = L::ld(upx, unit);
-            vuy = L::ld(upy, unit);
-        }
-        const V vlat = L::ld(lat, unit);
-        if constexpr (HAS_UP && HAS_UPC) vcu = L::ld(upc, unit);
-        if constexpr (HAS_LATC) vcl = L::ld(latc, unit);
-        // keep every load of the iteration ahead of the math: left alone, the scheduler sinks loads next to
-        // their first use to save registers in some instantiations (load -> wait -> use, five times over)
-        __builtin_amdgcn_sched_barrier(0);
-        const float yf = (float)y;
+    // this wave's job, the lane's place in its tile (once per kernel), its column terms, its first row
+    const int lane = tid & 63, wave = tid >> 6;
+    const int job = chunk * (kBlock / 64) + wave;        // jobs of an image: (rowblock, strip, wave of the tile)
+    const int tile = job / a.wpt, tw = job - tile * a.wpt;
+    const int rowblock = tile / a.nstrips, strip = tile - rowblock * a.nstrips;
+    const int f = tw * 64 + lane;                        // lane index inside the tile
+    const int tr = f / a.cu, tc = f - tr * a.cu;
+    const int xu = strip * a.cu + tc;                    // unit column of the lane
+    const bool live = job < a.jobs && tr < a.rpi && xu < a.wu;
+    const int y_end = min((rowblock + 1) * a.rows_per_block, a.H);
+    int y = rowblock * a.rows_per_block + tr;
+    uint32_t off = ((uint32_t)y * (uint32_t)a.W + (uint32_t)(xu * VEC)) * 4u;      // byte offset inside a plane (N < 2^30)
+    const uint32_t off_step = (uint32_t)a.rpi * (uint32_t)a.W * 4u;
+    F col_u[L::kPairs], col_px[L::kPairs];
+#pragma unroll
+    for (int k = 0; k < L::kPairs; ++k) {
+        col_u[k] = (L::xcoord(xu * VEC, k) - P.cx) * P.ifx;                           // camera.py:309-311
+        col_px[k] = vfma(col_u[k], vsplat(col_u[k], -P.gc), vsplat(col_u[k], P.ga));  // p_x = ga - gc u
+    }
+    if (live) {
+        for (; y < y_end; y += a.rpi, off += off_step) {
+            V vux, vuy, vcu = L::ones(), vcl = L::ones();
+            if constexpr (HAS_UP) {
+                vux = L::ld(upx, off);
+                vuy = L::ld(upy, off);
+            }
+            const V vlat = L::ld(lat, off);
+            if constexpr (HAS_UP && HAS_UPC) vcu = L::ld(upc, off);
+            if constexpr (HAS_LATC) vcl = L::ld(latc, off);
+            // keep every load of the iteration ahead of the math: left alone, the scheduler sinks loads next to
+            // their first use to save registers in some instantiations (load -> wait -> use, five times over)
+            __builtin_amdgcn_sched_barrier(0);
+            const float v = ((float)y - P.cy) * P.ify;
 #if GCLM_NOMATH     // measurement only: the memory-system ceiling of this exact access pattern
 #pragma unroll
-        for (int k = 0; k < L::kPairs; ++k)
-            acc[0] = acc[0] + (HAS_UP ? L::get(vux, k) + L::get(vuy, k) : F(0.f)) + L::get(vlat, k) + L::get(vcu, k) + L::get(vcl, k);
-        (void)yf;
-        (void)hk;
-        (void)P;
+            for (int k = 0; k < L::kPairs; ++k)
+                acc[0] = acc[0] + (HAS_UP ? L::get(vux, k) + L::get(vuy, k) : F(0.f)) + L::get(vlat, k) + L::get(vcu, k) + L::get(vcl, k);
+            (void)v;
+            (void)hk;
 #else
 #pragma unroll
-        for (int k = 0; k < L::kPairs; ++k) {
-            if constexpr (MODEL == GCLM_PINHOLE || MODEL == GCLM_SIMPLE_RADIAL)
-                pixel_accumulate_fast<MODEL, HAS_UP, LOGF, F>(P, hk, L::xcoord(x, k), yf, HAS_UP ? L::get(vux, k) : F(0.f),
-                                                        HAS_UP ? L::get(vuy, k) : F(0.f), L::get(vlat, k),
-                                                        L::get(vcu, k), L::get(vcl, k), acc);
-            else
-                pixel_accumulate<MODEL, HAS_UP, LOGF, F>(P, hk, L::xcoord(x, k), yf, HAS_UP ? L::get(vux, k) : F(0.f),
-                                                   HAS_UP ? L::get(vuy, k) : F(0.f), L::get(vlat, k), L::get(vcu, k),
-                                                   L::get(vcl, k), acc);
-        }
+            for (int k = 0; k < L::kPairs; ++k) {
+                if constexpr (MODEL == GCLM_PINHOLE || MODEL == GCLM_SIMPLE_RADIAL)
+                    pixel_accumulate_fast<MODEL, HAS_UP, LOGF, F>(P, hk, col_u[k], col_px[k], v, HAS_UP ? L::get(vux, k) : F(0.f),
+                                                            HAS_UP ? L::get(vuy, k) : F(0.f), L::get(vlat, k),
+                                                            L::get(vcu, k), L::get(vcl, k), acc);
+                else
+                    pixel_accumulate<MODEL, HAS_UP, LOGF, F>(P, hk, col_u[k], col_px[k], v, HAS_UP ? L::get(vux, k) : F(0.f),
+                                                       HAS_UP ? L::get(vuy, k) : F(0.f), L::get(vlat, k), L::get(vcu, k),
+                                                       L::get(vcl, k), acc);
+            }
 #endif
-        x += dx;
-        y += dy;
-        if (x >= a.W) {
-            x -= a.W;
-            ++y;
         }
     }
 
-    // wave64 butterfly, then the 4 waves through LDS; one record per workgroup
+    // wave64 DPP sum, then the 4 waves through LDS; one record per workgroup
     __shared__ float red[kBlock / 64][NACC];
-    const int lane = tid & 63, wave = tid >> 6;
     float wsum[NACC];            // all sums first, ONE predicated store block: the 16 DPP chains interleave
 #pragma unroll
     for (int i = 0; i < NACC; ++i) wsum[i] = wave_sum(hsum(acc[i]));
@@ -849,7 +864,8 @@ __global__ __launch_bounds__(kBlock) void jacobian_kernel(const float* cam, cons
     HuberK hk{1.f, 1.f, 1.f, 1.f};
     float acc[NACC];
     const size_t px = (size_t)b * N + i;
-    pixel_accumulate<MODEL, true, false, float, 1>(P, hk, (float)x, (float)y, 0.f, 0.f, 0.f, 1.f, 1.f, acc,
+    const float u = ((float)x - P.cx) * P.ifx, v = ((float)y - P.cy) * P.ify;
+    pixel_accumulate<MODEL, true, false, float, 1>(P, hk, u, fmaf(u, -P.gc, P.ga), v, 0.f, 0.f, 0.f, 1.f, 1.f, acc,
                                                       J_up ? J_up + px * 2 * PN : nullptr,
                                                       J_lat ? J_lat + px * PN : nullptr);
 }
@@ -884,7 +900,8 @@ __global__ __launch_bounds__(kBlock) void residual_kernel(const float* up, const
     const size_t px = (size_t)b * N + i;
     const float dux = up ? up[(size_t)b * 2 * N + i] : 0.f, duy = up ? up[(size_t)b * 2 * N + N + i] : 0.f;
     const float dl = lat ? lat[px] : 0.f;
-    pixel_accumulate<MODEL, true, false, float, 2>(P, hk, (float)x, (float)y, dux, duy, dl, 1.f, 1.f, acc,
+    const float u = ((float)x - P.cx) * P.ifx, v = ((float)y - P.cy) * P.ify;
+    pixel_accumulate<MODEL, true, false, float, 2>(P, hk, u, fmaf(u, -P.gc, P.ga), v, dux, duy, dl, 1.f, 1.f, acc,
                                                    r_up ? r_up + px * 2 : nullptr, r_lat ? r_lat + px : nullptr);
 }
 

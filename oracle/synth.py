@@ -50,3 +50,29 @@ def make_fields(seed: int, indices, camera_model: str, H: int, W: int, noise: fl
     if confidences:
         data |= {"up_confidence": upc, "latitude_confidence": latc}
     return data, cams.astype(np.float32), gravs.astype(np.float32)
+
+
+def make_shared_group(seed: int, group: int, camera_model: str, H: int, W: int, frames: int = 16,
+                      noise: float = 0.02):
+    """Fields of ONE shared-intrinsics group (BASELINE configs[4]: 16 frames of one camera): the intrinsics are
+    those of image index 10_000 + group, the gravity of frame i is that of image index (10_000 + group) * 64 + i;
+    noise / confidences are keyed by the frame's own index, so every frame is a function of (seed, group, i)."""
+    base = 10_000 + group
+    cam0 = gt_params(seed, base, camera_model, H, W)[0]
+    idx = [base * 64 + i for i in range(frames)]
+    cams = np.stack([cam0] * frames)
+    gravs = np.stack([gt_params(seed, j, camera_model, H, W)[1] for j in idx])
+    up, lat = lm_oracle.render(camera_model, H, W, cams, gravs, precision="f64")
+    upc = np.empty((frames, H, W), np.float32)
+    latc = np.empty((frames, H, W), np.float32)
+    for k, j in enumerate(idx):
+        rng = np.random.default_rng([seed, j, 1])
+        up[k] += rng.normal(0, noise, up[k].shape).astype(np.float32)
+        lat[k] += rng.normal(0, noise, lat[k].shape).astype(np.float32)
+        upc[k] = rng.uniform(0, 1, (H, W)).astype(np.float32)
+        latc[k] = rng.uniform(0, 1, (H, W)).astype(np.float32)
+    up /= np.sqrt((up.astype(np.float64) ** 2).sum(1, keepdims=True)).astype(np.float32)
+    lim = np.float32(np.pi / 2 - 1e-3)
+    lat = np.clip(lat, -lim, lim)
+    data = {"up_field": up, "latitude_field": lat, "up_confidence": upc, "latitude_confidence": latc}
+    return data, cams.astype(np.float32), gravs.astype(np.float32)

@@ -1,29 +1,74 @@
-"""Instruction statistics of the sweep kernel's main loop (run in the build container).
-usage: python scripts/isa_stats.py [mangled-name-substring ...]"""
-import collections, os, re, subprocess, sys
+"""Instruction statistics of the sweep kernel's main loop (run in the build container: hipcc cross-compiles).
+
+usage: python scripts/isa_stats.py [--json OUT] [--dump SYMBOL_SUBSTRING] [MODEL ...]
+       MODEL in {0 pinhole, 1 simple_radial, 2 radial, 3 simple_divisional}; default: all four.
+Looks at the instantiation sweep_kernel<MODEL, HAS_UP=1, HAS_UPC=1, HAS_LATC=1, LOGF=1, VEC=4> (the loop sweep of the
+default conf with both confidences: what bench.py runs) by its mangled template arguments, independent of how many
+template parameters precede / follow them.  EXTRA="-D..." adds compile flags (A/B switches of gclm_pass.hip)."""
+import collections
+import json
+import os
+import re
+import subprocess
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "geocalib_amd", "csrc", "gclm_pass.hip")
 asm = "/tmp/gclm_pass.s"
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", *os.environ.get("EXTRA","").split(), "-S",
-                "--cuda-device-only", "-o", asm, src], check=True, capture_output=True)
-text = open(asm).read()
-wanted = sys.argv[1:] or ["ILi0ELb1ELb1ELb1ELi4E", "ILi1ELb1ELb1ELb1ELi4E"]
-for w in wanted:
-    m = re.search(r"^(_ZN4gclm\S*sweep_kernel%s\S*):\s*;.*?\n(.*?)\.amdhsa_kernel" % w, text, re.S | re.M)
-    if not m:
-        print("not found", w); continue
-    body = m.group(2).split("\n")
-    labels = {mm.group(1): i for i, l in enumerate(body) if (mm := re.match(r"^(\.LBB\d+_\d+):", l))}
-    loops = [(labels[mm.group(1)], i) for i, l in enumerate(body)
-             if (mm := re.search(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", l)) and labels.get(mm.group(1), 1 << 30) < i]
-    vg = re.search(r"\.vgpr_count:\s+(\d+)", text[m.end():m.end() + 8000])
-    nv = re.search(r"; NumVgprs: (\d+)", text[m.start():m.end() + 4000])
-    a, b = max(loops, key=lambda t: t[1] - t[0])
-    ops = [l.strip().split()[0] for l in body[a:b + 1] if l.startswith("\t") and not l.strip().startswith((".", ";"))]
-    c = collections.Counter(ops)
-    valu = sum(v for k, v in c.items() if k.startswith("v_"))
-    pk = sum(v for k, v in c.items() if k.startswith("v_pk_"))
-    trans = sum(v for k, v in c.items() if re.match(r"v_(rsq|sqrt|rcp|exp|log|sin|cos)", k))
-    mov = sum(v for k, v in c.items() if "mov" in k)
-    print(f"{w}: loop {len(ops)} instr, VALU {valu} (packed {pk}, trans {trans}, mov {mov}) -> {valu/4:.1f} VALU/px; NumVgprs {nv.group(1) if nv else '?'}")
-    print("   ", c.most_common(14))
+NAMES = {0: "pinhole", 1: "simple_radial", 2: "radial", 3: "simple_divisional"}
+
+
+def main():
+    args = sys.argv[1:]
+    out_json = dump = None
+    if "--json" in args:
+        i = args.index("--json"); out_json = args[i + 1]; del args[i:i + 2]
+    if "--dump" in args:
+        i = args.index("--dump"); dump = args[i + 1]; del args[i:i + 2]
+    models = [int(a) for a in args] or [0, 1, 2, 3]
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast",
+                    "-fno-slp-vectorize", *os.environ.get("EXTRA", "").split(), "-S", "--cuda-device-only", "-o", asm, src],
+                   check=True, capture_output=True)
+    text = open(asm).read()
+    results = {}
+    for m_id in models:
+        # sweep_kernel<MODEL, true, true, true, true(LOGF), 4(VEC)>
+        pat = r"^(_ZN4gclm\S*sweep_kernelILi%dELb1ELb1ELb1ELb1ELi4E\S*):\s*;.*?\n(.*?)\.amdhsa_kernel" % m_id
+        m = re.search(pat, text, re.S | re.M)
+        if not m:
+            print(f"model {m_id}: instantiation not found (template signature changed?)")
+            sys.exit(1)
+        body = m.group(2).split("\n")
+        labels = {mm.group(1): i for i, l in enumerate(body) if (mm := re.match(r"^(\.LBB\d+_\d+):", l))}
+        loops = [(labels[mm.group(1)], i) for i, l in enumerate(body)
+                 if (mm := re.search(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", l)) and labels.get(mm.group(1), 1 << 30) < i]
+        tail = text[m.end():m.end() + 8000]
+        nv = re.search(r"\.amdhsa_next_free_vgpr\s+(\d+)", tail)
+        sc = re.search(r"; ScratchSize: (\d+)", text[m.start():m.end() + 6000])
+        a, b = max(loops, key=lambda t: t[1] - t[0])
+        ops = [l.strip().split()[0] for l in body[a:b + 1] if l.startswith("\t") and not l.strip().startswith((".", ";"))]
+        c = collections.Counter(ops)
+        valu = sum(v for k, v in c.items() if k.startswith("v_"))
+        pk = sum(v for k, v in c.items() if k.startswith("v_pk_"))
+        trans = sum(v for k, v in c.items() if re.match(r"v_(rsq|sqrt|rcp|exp|log|sin|cos)", k))
+        mov = sum(v for k, v in c.items() if "mov" in k)
+        loads = sum(v for k, v in c.items() if k.startswith("global_load"))
+        mfma = sum(v for k, v in c.items() if "mfma" in k)
+        results[NAMES[m_id]] = {"loop_instructions": len(ops), "valu": valu, "valu_packed": pk, "valu_transcendental": trans,
+                                "valu_mov": mov, "global_loads": loads, "mfma": mfma, "pixels_per_iteration": 4,
+                                "vgprs": int(nv.group(1)) if nv else None, "scratch_bytes": int(sc.group(1)) if sc else None,
+                                "top": c.most_common(12)}
+        print(f"{NAMES[m_id]}: loop {len(ops)} instr, VALU {valu} (packed {pk}, trans {trans}, mov {mov}), "
+              f"{loads} global loads, {mfma} mfma -> {valu / 4:.1f} VALU/px; VGPRs {nv.group(1) if nv else '?'}, "
+              f"scratch {sc.group(1) if sc else '?'} B")
+        print("   ", c.most_common(12))
+        if dump and dump in m.group(1):
+            print("\n".join(body[a:b + 1]))
+    if out_json:
+        with open(out_json, "w") as fh:
+            json.dump({"kernel": "gclm::sweep_kernel<MODEL, up, up_conf, lat_conf, log-focal, float4>", "flags": os.environ.get("EXTRA", ""),
+                       "models": results}, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()

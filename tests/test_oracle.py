@@ -190,3 +190,22 @@ def test_oracle_matches_reference_shared_radial(oracle):
     conf = {"camera_model": "radial", "shared_intrinsics": True, "num_steps": 20, "early_stop": False}
     out = oracle.solve(data_for("radial", "bench"), conf, precision="f32")
     compare_result(out, ref, {**TIGHT, "cost": 2e-4, "cov": 1e-3, "unc": 2e-3}, "radial/shared")
+
+
+@pytest.mark.parametrize("model", ["pinhole", "simple_radial"])
+def test_oracle_matches_reference_shared16_at_shape(oracle, model):
+    """BASELINE configs[4] at its stated shape: ONE shared-intrinsics group of 16 frames at 640x480, 20 iterations,
+    against the reference's own output (tests/golden/make_golden_shared16.py; lm_optimizer.py:350-383, 597-603)."""
+    from oracle import synth
+    g = np.load(os.path.join(GOLDEN, "golden_shared16.npz"))
+    data, cams, gravs = synth.make_shared_group(1234, 0, model, 480, 640, frames=16)
+    chk = np.array([np.float64(np.asarray(v, np.float64).sum()) for _, v in sorted(data.items())])
+    assert np.allclose(chk, g[f"{model}/g0/input_checksum"], rtol=1e-9, atol=1e-3), "regenerated inputs drifted"
+    conf = {"camera_model": model, "shared_intrinsics": True, "num_steps": 20, "early_stop": False}
+    out = oracle.solve(data, conf, precision="f32")
+    ref = {k.split("/", 2)[2]: g[k] for k in g.files if k.startswith(f"{model}/g0/")}
+    compare_result(out, ref, TIGHT, f"shared16/{model}")
+    assert np.array_equal(out["stop_at"], ref["stop_at"])
+    # one camera for the whole group, and it is the ground truth up to the noise level
+    assert np.abs(out["camera"][:, 2:4] - out["camera"][0, 2:4]).max() == 0
+    assert np.abs(out["camera"][0, 3] / cams[0, 3] - 1) < 2e-3
