@@ -14,7 +14,14 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline:     achieved = algorithmic bytes of one sweep launch / mean sweep duration measured with
                 HIP events on the launch stream inside the timed region; peak = 8 TB/s HBM3E.
   cpu_baseline: the CPU oracle (oracle/lm_oracle.c, a port of the reference algorithm) on a bounded
-                sample of the same workload, on this box's host cores (rank 0, N=1 only).
+                sample of the same workload, on this box's host cores (rank 0, N=1 only), and beside it
+                `reference_torch`: the reference's OWN PyTorch CPU path (geocalib/lm_optimizer.py:141, .eval(),
+                no_grad), measured where the reference exists -- the build container -- by
+                scripts/cpu_reference_torch.py and read from profiles/cpu_reference_torch.json (hardware named).
+The timed region (exactly --steps steps between barrier + synchronize) is run --repeats times; `value` and
+`ms_per_step` are the MEDIAN region (a 0.2-0.4 s window has a few % of run-to-run variance), all regions are listed.
+For N > 1 the line also carries `multi_gpu`: ranks_seen (from the communicator), per_rank_ms (every rank's own
+median step time) and collective_ms (device time inside the collectives per step, max over ranks).
 """
 import argparse
 import ctypes as C
@@ -40,6 +47,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each; the median is reported")
     ap.add_argument("--batch", type=int, default=1024, help="images per GPU")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
@@ -66,9 +74,31 @@ def cpu_baseline(args, n_images):
     t0 = time.perf_counter()
     lm_oracle.solve(data, conf, precision="f32", num_threads=cores)
     dt = time.perf_counter() - t0
-    return {"value": round(n_images / dt, 3), "unit": "images/sec", "cores": min(cores, n_images), "kind": "port",
-            "sample": f"{n_images} images {args.width}x{args.height}, {args.lm_steps} LM iters, oracle/lm_oracle.c "
-                      f"(float32, OpenMP over images), {dt:.1f} s"}
+    out = {"value": round(n_images / dt, 3), "unit": "images/sec", "cores": min(cores, n_images), "kind": "port",
+           "sample": f"{n_images} images {args.width}x{args.height}, {args.lm_steps} LM iters, oracle/lm_oracle.c "
+                     f"(float32, OpenMP over images), {dt:.1f} s"}
+    ref = reference_torch(args)
+    if ref is not None:
+        out["reference_torch"] = ref
+    return out
+
+
+def reference_torch(args):
+    """The reference's own CPU PyTorch timing for this camera model, as measured by scripts/cpu_reference_torch.py in
+    the build container (the only place /root/reference exists); None when the file or the model is missing."""
+    path = os.path.join(ROOT, "profiles", "cpu_reference_torch.json")
+    if not os.path.exists(path) or (args.height, args.width, args.lm_steps) != (480, 640, 20):
+        return None
+    with open(path) as fh:
+        r = json.load(fh)
+    m = r.get("models", {}).get(args.camera_model)
+    if m is None:
+        return None
+    return {"value": m["images_per_sec"], "unit": "images/sec", "cores": r["cores"], "kind": "reference",
+            "code": "geocalib/lm_optimizer.py:141 LMOptimizer, .eval(), torch.no_grad(), CPU float32",
+            "measured_on": f"{r['host']}: {r['cpu']}, {r['cores']} threads, torch {r['torch']}",
+            "sample": f"{m['images']} images {r['width']}x{r['height']} in chunks of {r['chunk']}, {r['lm_steps']} LM iters, "
+                      f"{m['seconds']} s", "source": "profiles/cpu_reference_torch.json"}
 
 
 def ensure_built(local_rank: int) -> None:
@@ -113,7 +143,7 @@ def main():
 
     ensure_built(local_rank)
     from geocalib_amd import LMOptimizer, _lib
-    from geocalib_amd.parallel import SharedIntrinsicsSplit, calibrate_sharded
+    from geocalib_amd.parallel import CollectiveTimer, GatherPlan, SharedIntrinsicsSplit, calibrate_sharded
     from geocalib_amd.synth import synth_fields
 
     lib = _lib.load()
@@ -125,9 +155,11 @@ def main():
         # independent intrinsics: rank r owns the contiguous images [r*B, (r+1)*B)
         data, gt_cam, gt_grav = synth_fields(args.camera_model, B, H, W, dev, seed=args.seed, first_index=rank * B)
         opt = LMOptimizer(conf).eval()
+        ctimer = CollectiveTimer()
+        plan = GatherPlan(n_total, world, dev) if distributed else None      # exchange buffers live outside the timed loop
 
         def step():
-            return calibrate_sharded(opt, data, n_total)
+            return calibrate_sharded(opt, data, n_total, plan=plan, timer=ctimer)
     else:
         # shared intrinsics: n_total/gs groups; every rank holds gs/world frames of EVERY group
         assert gs % world == 0 and B % (gs // world) == 0, "group size must be divisible by the number of GPUs"
@@ -136,12 +168,13 @@ def main():
         data, gt_cam, gt_grav = synth_fields(args.camera_model, B, H, W, dev, seed=args.seed, first_index=rank * fpg,
                                              group_size=gs, run=fpg, run_stride=gs)
         opt = LMOptimizer({**conf, "shared_intrinsics": True, "group_size": gs}).eval()
+        ctimer = CollectiveTimer()
         if not distributed:
             def step():
                 return opt(data)
         else:
             gof = torch.arange(B, device=dev, dtype=torch.int32) // fpg
-            split = SharedIntrinsicsSplit(opt, n_groups)
+            split = SharedIntrinsicsSplit(opt, n_groups, timer=ctimer)
 
             def step():
                 return split(data, gof)
@@ -149,26 +182,40 @@ def main():
     for _ in range(max(args.warmup, 1)):
         out = step()
     torch.cuda.synchronize()
+    ctimer.total_ms()                                     # drop the warm-up's collective events
     handle = opt._handle(dev)
     if not args.no_timing:
         lib.gclm_set_timing(handle.ptr, 1)
 
+    regions = []                                          # seconds per timed region of exactly --steps steps
+    for _ in range(max(args.repeats, 1)):
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        regions.append(time.perf_counter() - t0)
+    own = sorted(regions)[len(regions) // 2]              # this rank's median region
+    coll_ms = ctimer.total_ms() / (len(regions) * args.steps)
+    ranks_seen, per_rank_ms, coll_ms_max = world, [own / args.steps * 1e3], coll_ms
     if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
+        tdev = dev if args.backend == "nccl" else "cpu"
+        t = torch.tensor(regions, device=tdev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)           # every region: MAX over ranks, then the median region
+        regions = t.tolist()
+        ranks_seen = dist.get_world_size()
+        mine = torch.tensor([own / args.steps * 1e3, coll_ms], device=tdev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(ranks_seen)]
+        dist.all_gather(allr, mine)
+        per_rank_ms = [round(x[0].item(), 4) for x in allr]
+        coll_ms_max = max(x[1].item() for x in allr)
+    elapsed = sorted(regions)[len(regions) // 2]
     sweep_ms, sweep_n = 0.0, 0
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
-    if not args.no_timing:   # HIP events recorded around every sweep launch of the timed region
+    if not args.no_timing:   # HIP events recorded around every sweep launch of the timed regions
         n, ms = C.c_int(0), C.c_float(0)
         _lib.check(lib.gclm_last_pass_timing(handle.ptr, C.byref(n), C.byref(ms)), handle.ptr, "timing")
         sweep_ms, sweep_n = ms.value, n.value
@@ -187,6 +234,7 @@ def main():
             "metric": "images/sec LM calibration (640x480, 20 iters)", "value": round(value, 1),
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "repeats": len(regions), "ms_per_step_repeats": [round(r / args.steps * 1e3, 4) for r in regions],
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"BASELINE configs[{1 if world == 1 else 2}]: batch={B}/GPU ({n_total} total) "
                                     if gs == 0 else
@@ -202,6 +250,14 @@ def main():
                                        f"frames of every group split x{world}, one all-reduce per LM step")},
             "check": {"median_focal_rel_err_vs_gt": f_err, "median_gravity_abs_err_vs_gt": g_err},
         }
+        if distributed:
+            result["multi_gpu"] = {
+                "ranks_seen": ranks_seen, "per_rank_ms": per_rank_ms,
+                "collective": "all_gather of packed result rows" if gs == 0 else "all_reduce(sum) of per-group Schur partials",
+                "collectives_per_step": 1 if gs == 0 else args.lm_steps,
+                "collective_bytes": (n_total * 4 * (8 + 3 + _lib.INFO_STRIDE) if gs == 0
+                                     else (n_total // gs) * 4 * _lib.SHARED_PARTIAL_STRIDE),
+                "collective_ms": round(coll_ms_max, 4), "backend": args.backend}
         if sweep_n:
             avg_ms = sweep_ms / sweep_n
             achieved = algo_bytes_per_launch / (avg_ms * 1e-3) / 1e9

@@ -73,6 +73,23 @@ const char* validate(const gclm_config& c) {
     return nullptr;
 }
 
+// Every entry point runs on the handle's device and leaves the CALLER's current device as it found it (a
+// single-process multi-GPU program would otherwise see its default device flip under PyTorch, also at garbage-
+// collection time through gclm_destroy).
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t status = hipSuccess;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) status = hipSetDevice(device); else prev = -1;    // prev = -1: nothing to restore
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 bool is_aligned16(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -263,7 +280,7 @@ int gclm_configure(gclm_handle* h, const gclm_config* cfg) {
 
 int gclm_destroy(gclm_handle* h) {
     if (!h) return 0;
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard(h->device);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     if (h->ws) (void)hipFree(h->ws);
     delete h;
@@ -304,7 +321,8 @@ static int run_solve(gclm_handle* h, const float* d_up, const float* d_lat, cons
     if (!d_cam_out || !d_grav_out || !d_info_out) return fail(h, -3, "null output pointer");
     if (B == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    GCLM_HIP(h, hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
+    GCLM_HIP(h, guard.status);
     const bool al = is_aligned16(d_up) && is_aligned16(d_lat) && is_aligned16(d_up_conf) && is_aligned16(d_lat_conf);
     const Geometry geo = plan_geometry(B, H, W, al);
     SolveCtx& c = h->ctx;
@@ -322,8 +340,7 @@ static int run_solve(gclm_handle* h, const float* d_up, const float* d_lat, cons
         if (!h->cfg.shared_intrinsics) {
             GCLM_HIP(h, launch_update(c, step, s));
         } else {
-            GCLM_HIP(h, launch_shared_reduce(c, step, h->group_partials, s));
-            GCLM_HIP(h, launch_shared_apply(c, step, h->group_partials, s));
+            GCLM_HIP(h, launch_shared_step(c, step, s));     // reduce + Schur solve + update: one launch
         }
     }
     GCLM_HIP(h, launch_prep_final(c, s));
@@ -373,7 +390,8 @@ int gclm_system(gclm_handle* h, const float* d_up, const float* d_lat, const flo
     if (!d_cam || !d_grav || !d_cost || !d_grad || !d_hess) return fail(h, -3, "gclm_system: null pointer");
     if (B == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    GCLM_HIP(h, hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
+    GCLM_HIP(h, guard.status);
     const bool al = is_aligned16(d_up) && is_aligned16(d_lat) && is_aligned16(d_up_conf) && is_aligned16(d_lat_conf);
     const Geometry geo = plan_geometry(B, H, W, al);
     SolveCtx& c = h->ctx;
@@ -398,7 +416,8 @@ int gclm_shared_begin(gclm_handle* h, const float* d_up, const float* d_lat, con
     if (int rc = check_shapes(h, d_lat, B_local, H, W)) return rc;
     if (!d_cam_io || !d_grav_io || !d_group_of_frame || num_groups <= 0) return fail(h, -3, "gclm_shared_begin: bad arguments");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    GCLM_HIP(h, hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
+    GCLM_HIP(h, guard.status);
     const bool al = is_aligned16(d_up) && is_aligned16(d_lat) && is_aligned16(d_up_conf) && is_aligned16(d_lat_conf);
     const int Bp = B_local > 0 ? B_local : 1;
     h->sh.geo = plan_geometry(Bp, H, W, al);
@@ -422,7 +441,8 @@ int gclm_shared_reduce(gclm_handle* h, int step, float* d_partials, void* stream
     if (!h->sh.active) return fail(h, -4, "gclm_shared_reduce: no active session (call gclm_shared_begin)");
     if (!d_partials || step < 0 || step >= h->cfg.num_steps) return fail(h, -3, "gclm_shared_reduce: bad arguments");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    GCLM_HIP(h, hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
+    GCLM_HIP(h, guard.status);
     SolveCtx& c = h->ctx;
     if (c.B > 0) {
         const SweepArgs a = sweep_args(h, h->sh.up, h->sh.lat, h->sh.upc, h->sh.latc, c.pb[step & 1], h->sh.geo, true, 0);
@@ -437,7 +457,8 @@ int gclm_shared_apply(gclm_handle* h, int step, const float* d_partials, void* s
     if (!h->sh.active) return fail(h, -4, "gclm_shared_apply: no active session");
     if (!d_partials || step < 0 || step >= h->cfg.num_steps) return fail(h, -3, "gclm_shared_apply: bad arguments");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    GCLM_HIP(h, hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
+    GCLM_HIP(h, guard.status);
     if (h->ctx.B > 0) GCLM_HIP(h, launch_shared_apply(h->ctx, step, d_partials, s));
     return 0;
 }
@@ -447,7 +468,8 @@ int gclm_shared_finish(gclm_handle* h, float* d_info_out, void* stream) {
     if (!h->sh.active) return fail(h, -4, "gclm_shared_finish: no active session");
     if (!d_info_out) return fail(h, -3, "gclm_shared_finish: null info pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    GCLM_HIP(h, hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
+    GCLM_HIP(h, guard.status);
     SolveCtx& c = h->ctx;
     h->sh.active = false;
     if (c.B == 0) return 0;

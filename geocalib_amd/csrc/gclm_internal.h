@@ -135,6 +135,7 @@ hipError_t launch_prep_final(const SolveCtx& c, hipStream_t s);
 hipError_t launch_finalize(const SolveCtx& c, float* d_cam, float* d_grav, float* d_info, hipStream_t s);
 hipError_t launch_shared_reduce(const SolveCtx& c, int step, float* d_group_partials, hipStream_t s);
 hipError_t launch_shared_apply(const SolveCtx& c, int step, const float* d_group_partials, hipStream_t s);
+hipError_t launch_shared_step(const SolveCtx& c, int step, hipStream_t s);
 hipError_t launch_system_out(const SolveCtx& c, float* d_cost, float* d_grad, float* d_hess, hipStream_t s);
 hipError_t launch_pblock_from_params(const SolveCtx& c, const float* d_cam, const float* d_grav, int as_rpf, PBlock* out, hipStream_t s);
 hipError_t launch_upsample(const float* src, int planes, int h, int w, int H, int W, float* dst, hipStream_t s);

@@ -273,24 +273,6 @@ __global__ __launch_bounds__(kGroups * kSlots) void finalize_kernel(SolveCtx c, 
 // which is algebraically the same solve and reduces over frames with a plain SUM -- i.e. it can
 // be all-reduced across devices when a group's frames are sharded (BASELINE config 5).
 
-// per frame: reduce partials -> frame_sys, costs / allclose bookkeeping
-__global__ __launch_bounds__(kGroups * kSlots) void shared_frame_kernel(SolveCtx c, int step) {
-    if (c.cfg.early_stop && stop_fired_before(c.ctrl, step)) return;
-    int b;
-    float acc[kNAccMax];
-    if (!coop_reduce_partials(c.partials, c.B, c.nchunks, acc_floats(c.cfg.camera_model), b, acc)) return;
-    State s = c.state[step & 1][b];
-    const float invN = 1.0f / (float)((size_t)c.H * c.W);
-    float cu, cl;
-    const float total = total_cost(acc, invN, true, cu, cl);
-    if (step == 0) { s.init_cu = cu; s.init_cl = cl; }     // infos["initial_*"] (:585-588)
-    cost_bookkeeping(c.cfg, c.ctrl, step, total, s, false);   // lambda is never updated (:612)
-    c.state[step & 1][b] = s;
-    const int nacc = acc_floats(c.cfg.camera_model);
-    float* out = c.frame_sys + (size_t)b * nacc;
-    for (int q = 0; q < nacc; ++q) out[q] = acc[q];
-}
-
 __device__ inline int lower_bound(const int32_t* a, int n, int key) {
     int lo = 0, hi = n;
     while (lo < hi) {
@@ -315,58 +297,18 @@ __device__ inline bool frame_block(const float (&Hf)[PM][PM], float lambda, floa
     return true;
 }
 
-// per group: local Schur partials over this device's frames of the group (ni = 1..3 shared intrinsics)
-//   layout (GCLM_SHARED_PARTIAL_STRIDE = 32 floats): [0..9) sum E^T Dinv E (3x3 row-major), [9..12) sum E^T Dinv g,
-//   [12..21) sum H_ii, [21..24) sum g_i, [24] #frames; NaN in [0] marks a non-PD frame block.
-constexpr int kNI = 3, kGS = 0, kGR = 9, kGC = 12, kGc = 21, kGN = 24;
-template <int PM, int NI>
-__global__ void shared_group_kernel(SolveCtx c, int step, float* gp) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= c.n_groups) return;
-    if (c.cfg.early_stop && stop_fired_before(c.ctrl, step)) return;
-    constexpr int ni = NI;
-    const int nacc = acc_floats(c.cfg.camera_model);
-    int f0, f1;
-    group_range(c, g, f0, f1);
-    float S[kNI][kNI] = {}, r[kNI] = {}, C[kNI][kNI] = {}, cg[kNI] = {};
-    bool ok = true;
-    for (int f = f0; f < f1; ++f) {
-        float Hf[PM][PM], Gf[PM], Dinv[2][2];
-        unpack_system<PM>(c.frame_sys + (size_t)f * nacc, Hf, Gf);
-        ok = frame_block<PM>(Hf, c.state[step & 1][f].lambda, Dinv) && ok;
-        const float q0 = Dinv[0][0] * Gf[0] + Dinv[0][1] * Gf[1], q1 = Dinv[1][0] * Gf[0] + Dinv[1][1] * Gf[1];
-        for (int i = 0; i < ni; ++i) {
-            const float e0 = Hf[0][2 + i], e1 = Hf[1][2 + i];                         // E[:, i]
-            const float t0 = Dinv[0][0] * e0 + Dinv[0][1] * e1, t1 = Dinv[1][0] * e0 + Dinv[1][1] * e1;
-            for (int j = 0; j < ni; ++j) S[j][i] += Hf[0][2 + j] * t0 + Hf[1][2 + j] * t1;
-            r[i] += e0 * q0 + e1 * q1;
-            cg[i] += Gf[2 + i];
-            for (int j = 0; j < ni; ++j) C[i][j] += Hf[2 + i][2 + j];
-        }
-    }
-    float* o = gp + (size_t)g * GCLM_SHARED_PARTIAL_STRIDE;
-    for (int i = 0; i < GCLM_SHARED_PARTIAL_STRIDE; ++i) o[i] = 0.f;
-    for (int i = 0; i < ni; ++i) {
-        o[kGR + i] = r[i];
-        o[kGc + i] = cg[i];
-        for (int j = 0; j < ni; ++j) { o[kGS + i * kNI + j] = S[i][j]; o[kGC + i * kNI + j] = C[i][j]; }
-    }
-    if (!ok) o[0] = __builtin_nanf("");
-    o[kGN] = (float)(f1 - f0);
-}
+// Schur partials of one group (ni = 1..3 shared intrinsics), GCLM_SHARED_PARTIAL_STRIDE = 32 floats:
+//   [0..9) sum E^T Dinv E (3x3 row-major), [9..12) sum E^T Dinv g, [12..21) sum H_ii, [21..24) sum g_i, [24] #frames;
+//   NaN in [0] marks a non-PD frame block.
+constexpr int kNI = 3, kGS = 0, kGR = 9, kGC = 12, kGc = 21, kGN = 24, kGSum = 24;
 
-// per frame: solve the (tiny) Schur system of its group from the REDUCED partials (redundantly per
-// frame: ni <= 3), back-substitute its own gravity block, update (lm_optimizer.py:597-606).
+// One frame's step from the REDUCED partials `o` of its group: solve the (tiny) Schur system (redundantly per frame:
+// ni <= 3), back-substitute the frame's own gravity block, update (lm_optimizer.py:597-606).
 template <int PM, int NI>
-__global__ void shared_apply_kernel(SolveCtx c, int step, const float* gp) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= c.B) return;
-    if (c.cfg.early_stop && stop_fired_before(c.ctrl, step)) return;
+__device__ inline void apply_shared_frame(const SolveCtx& c, int step, int b, const float* o) {
     const gclm_config& cfg = c.cfg;
     constexpr int ni = NI;
-    const int g = c.group_of_frame ? c.group_of_frame[b] : b / c.group_size;
     State s = c.state[step & 1][b];
-    const float* o = gp + (size_t)g * GCLM_SHARED_PARTIAL_STRIDE;
     float A[NI][NI], dS[NI], dI[kNI] = {}, dG[2] = {0.f, 0.f};
     bool ok = o[0] == o[0];
 #pragma unroll
@@ -399,6 +341,109 @@ __global__ void shared_apply_kernel(SolveCtx c, int step, const float* gp) {
     PBlock p;
     build_pblock(s, cfg.use_spherical_manifold != 0, cfg.use_log_focal != 0, p);
     c.pb[(step + 1) & 1][b] = p;
+}
+
+// ONE workgroup per group, cooperative over its frames (tiles of kTileFrames):
+//   (1) reduce the sweep's partial records of 8 frames at a time (thread = (frame, slot), fixed chunk order, double),
+//   (2) one thread per frame: mean costs / allclose bookkeeping, the frame's damped 2x2 block and its contribution
+//       to the group's Schur partials,
+//   (3) 24 threads sum the contributions over the frames in frame order (fp32, bit-reproducible),
+//   then either write the partials for the all-reduce of the split protocol (APPLY = false: gclm_shared_reduce), or --
+//   single device, the partials are already complete -- go straight on to the solve and the per-frame update
+//   (APPLY = true): a shared-intrinsics LM step is sweep + THIS kernel, the same two launches as an independent one.
+constexpr int kTileFrames = 64;
+template <int PM, int NI, bool APPLY>
+__global__ __launch_bounds__(kGroups * kSlots) void shared_step_kernel(SolveCtx c, int step, float* gp) {
+    if (c.cfg.early_stop && stop_fired_before(c.ctrl, step)) return;          // block-uniform
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int nacc = acc_floats(c.cfg.camera_model);
+    __shared__ float fsys[kTileFrames][kNAccMax];        // reduced per-frame systems of the tile
+    __shared__ float contrib[kTileFrames][kGSum + 1];    // per-frame Schur contributions (+1: bank spread)
+    __shared__ int bad[kTileFrames];
+    __shared__ float gsum[GCLM_SHARED_PARTIAL_STRIDE];
+    int f0, f1;
+    group_range(c, g, f0, f1);
+    if (tid < GCLM_SHARED_PARTIAL_STRIDE) gsum[tid] = 0.f;
+    int any_bad = 0;                                     // thread 0 only
+    const int grp = tid / kSlots, slot = tid % kSlots;
+    const float invN = 1.0f / (float)((size_t)c.H * c.W);
+    for (int t0 = f0; t0 < f1; t0 += kTileFrames) {
+        const int nt = min(kTileFrames, f1 - t0);
+        // (1) partial records -> fsys (and frame_sys in memory for the apply step)
+        for (int base = 0; base < nt; base += kGroups) {
+            const int fl = base + grp;
+            if (fl < nt && slot < nacc) {
+                const int b = t0 + fl;
+                double d = 0.0;
+                const float* p = c.partials + (size_t)b * c.nchunks * nacc + slot;
+#pragma unroll 4
+                for (int q = 0; q < c.nchunks; ++q) d += p[(size_t)q * nacc];
+                fsys[fl][slot] = (float)d;
+                c.frame_sys[(size_t)b * nacc + slot] = (float)d;
+            }
+        }
+        __syncthreads();
+        // (2) per frame
+        if (tid < nt) {
+            const int b = t0 + tid;
+            State s = c.state[step & 1][b];
+            float cu, cl;
+            const float total = total_cost(fsys[tid], invN, true, cu, cl);
+            if (step == 0) { s.init_cu = cu; s.init_cl = cl; }     // infos["initial_*"] (:585-588)
+            cost_bookkeeping(c.cfg, c.ctrl, step, total, s, false);   // lambda is never updated (:612)
+            c.state[step & 1][b] = s;
+            float Hf[PM][PM], Gf[PM], Dinv[2][2];
+            unpack_system<PM>(fsys[tid], Hf, Gf);
+            const bool ok = frame_block<PM>(Hf, s.lambda, Dinv);
+            bad[tid] = ok ? 0 : 1;
+            float* o = contrib[tid];
+#pragma unroll
+            for (int i = 0; i < kGSum; ++i) o[i] = 0.f;
+            const float q0 = Dinv[0][0] * Gf[0] + Dinv[0][1] * Gf[1], q1 = Dinv[1][0] * Gf[0] + Dinv[1][1] * Gf[1];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const float e0 = Hf[0][2 + i], e1 = Hf[1][2 + i];                         // E[:, i]
+                const float t0_ = Dinv[0][0] * e0 + Dinv[0][1] * e1, t1_ = Dinv[1][0] * e0 + Dinv[1][1] * e1;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    o[kGS + j * kNI + i] = Hf[0][2 + j] * t0_ + Hf[1][2 + j] * t1_;
+                    o[kGC + i * kNI + j] = Hf[2 + i][2 + j];
+                }
+                o[kGR + i] = e0 * q0 + e1 * q1;
+                o[kGc + i] = Gf[2 + i];
+            }
+        }
+        __syncthreads();
+        // (3) sum over the frames of the tile, frame order
+        if (tid < kGSum) {
+            float a = gsum[tid];
+            for (int f = 0; f < nt; ++f) a += contrib[f][tid];
+            gsum[tid] = a;
+        }
+        if (tid == 0)
+            for (int f = 0; f < nt; ++f) any_bad |= bad[f];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (any_bad) gsum[0] = __builtin_nanf("");
+        gsum[kGN] = (float)(f1 - f0);
+    }
+    __syncthreads();
+    if constexpr (!APPLY) {
+        if (tid < GCLM_SHARED_PARTIAL_STRIDE) gp[(size_t)g * GCLM_SHARED_PARTIAL_STRIDE + tid] = gsum[tid];
+    } else {
+        for (int b = f0 + tid; b < f1; b += kGroups * kSlots) apply_shared_frame<PM, NI>(c, step, b, gsum);
+    }
+}
+
+// split protocol, after the all-reduce: per frame, from the REDUCED partials
+template <int PM, int NI>
+__global__ void shared_apply_kernel(SolveCtx c, int step, const float* gp) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= c.B) return;
+    if (c.cfg.early_stop && stop_fired_before(c.ctrl, step)) return;
+    const int g = c.group_of_frame ? c.group_of_frame[b] : b / c.group_size;
+    apply_shared_frame<PM, NI>(c, step, b, gp + (size_t)g * GCLM_SHARED_PARTIAL_STRIDE);
 }
 
 // ---------------------------------------------------------------- gclm_system() helpers
@@ -697,7 +742,7 @@ inline dim3 grid1(int n) { return dim3((n + 127) / 128); }
     hipLaunchKernelGGL(kernel, dim3(reduce_blocks((n), c.nchunks)), dim3(kGroups * kSlots), 0, s, __VA_ARGS__)
 
 hipError_t launch_init(const SolveCtx& c, const InitArgs& ia, hipStream_t s) {
-    GCLM_L(init_kernel, c.B, s, c, ia);
+    GCLM_L(init_kernel, c.B > 0 ? c.B : 1, s, c, ia);     // B = 0 (an empty shard of the split protocol): thread 0 still resets Ctrl
     return hipGetLastError();
 }
 hipError_t launch_update(const SolveCtx& c, int step, hipStream_t s) {
@@ -714,15 +759,27 @@ hipError_t launch_finalize(const SolveCtx& c, float* d_cam, float* d_grav, float
     else GCLM_LR(finalize_kernel<4>, c.B, s, c, d_cam, d_grav, d_info);
     return hipGetLastError();
 }
+#define GCLM_LG(kernel, s, ...) hipLaunchKernelGGL(kernel, dim3(c.n_groups), dim3(kGroups * kSlots), 0, s, __VA_ARGS__)
 hipError_t launch_shared_reduce(const SolveCtx& c, int step, float* d_group_partials, hipStream_t s) {
-    if (c.B > 0) GCLM_LR(shared_frame_kernel, c.B, s, c, step);
+    if (c.n_groups <= 0) return hipSuccess;
     switch (c.cfg.camera_model) {
-        case GCLM_PINHOLE: GCLM_L((shared_group_kernel<4, 1>), c.n_groups, s, c, step, d_group_partials); break;
-        case GCLM_RADIAL: GCLM_L((shared_group_kernel<5, 3>), c.n_groups, s, c, step, d_group_partials); break;
-        default: GCLM_L((shared_group_kernel<4, 2>), c.n_groups, s, c, step, d_group_partials); break;
+        case GCLM_PINHOLE: GCLM_LG((shared_step_kernel<4, 1, false>), s, c, step, d_group_partials); break;
+        case GCLM_RADIAL: GCLM_LG((shared_step_kernel<5, 3, false>), s, c, step, d_group_partials); break;
+        default: GCLM_LG((shared_step_kernel<4, 2, false>), s, c, step, d_group_partials); break;
     }
     return hipGetLastError();
 }
+// single device: reduce + solve + update of every group in ONE launch
+hipError_t launch_shared_step(const SolveCtx& c, int step, hipStream_t s) {
+    if (c.n_groups <= 0) return hipSuccess;
+    switch (c.cfg.camera_model) {
+        case GCLM_PINHOLE: GCLM_LG((shared_step_kernel<4, 1, true>), s, c, step, nullptr); break;
+        case GCLM_RADIAL: GCLM_LG((shared_step_kernel<5, 3, true>), s, c, step, nullptr); break;
+        default: GCLM_LG((shared_step_kernel<4, 2, true>), s, c, step, nullptr); break;
+    }
+    return hipGetLastError();
+}
+#undef GCLM_LG
 hipError_t launch_shared_apply(const SolveCtx& c, int step, const float* d_group_partials, hipStream_t s) {
     switch (c.cfg.camera_model) {
         case GCLM_PINHOLE: GCLM_L((shared_apply_kernel<4, 1>), c.B, s, c, step, d_group_partials); break;

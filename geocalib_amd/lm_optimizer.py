@@ -48,7 +48,8 @@ def get_trivial_estimation(data: Dict[str, torch.Tensor], camera_model) -> Tuple
 
 
 class _Handle:
-    """Owns one gclm_handle (per device)."""
+    """Owns one gclm_handle: one per (device, stream) -- the handle owns the whole solve workspace (states, parameter
+    blocks, partial records, early-stop counters), so two streams must never share one (include/gclm.h)."""
 
     def __init__(self, cfg: _lib.GclmConfig, device: torch.device):
         lib = _lib.load()
@@ -181,7 +182,8 @@ class LMOptimizer(nn.Module):
         self.num_steps = conf.num_steps
         self.set_camera_model(conf.camera_model)
         self.setup_optimization_and_priors(shared_intrinsics=conf.shared_intrinsics)
-        self._handles: Dict[int, _Handle] = {}
+        self._handles: Dict[Tuple[int, int], _Handle] = {}
+        self._warned_training = False
 
     # ------------------------------------------------------------------ reference API
     def set_camera_model(self, camera_model: str) -> None:
@@ -237,14 +239,26 @@ class LMOptimizer(nn.Module):
         cfg.compute_uncertainty = int(not self.training)
         return cfg
 
-    def _handle(self, device: torch.device) -> _Handle:
+    _MAX_HANDLES = 16      # workspaces kept alive per optimiser (each is O(B) small records; LRU beyond this)
+
+    def _handle(self, device: torch.device, stream: int = None) -> _Handle:
+        """The gclm_handle of (device, stream): solves issued from different torch streams (e.g. the CNN of batch k+1
+        overlapping the LM of batch k) get different workspaces; the same stream reuses its own, in order."""
         cfg = self._config()
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        h = self._handles.get(idx)
+        if stream is None:
+            stream = torch.cuda.current_stream(torch.device("cuda", idx)).cuda_stream
+        key = (idx, int(stream))
+        h = self._handles.pop(key, None)
         if h is None:
-            h = self._handles[idx] = _Handle(cfg, torch.device("cuda", idx))
+            while len(self._handles) >= self._MAX_HANDLES:      # drop the least recently used (its stream may be gone)
+                old = self._handles.pop(next(iter(self._handles)))
+                torch.cuda.synchronize(torch.device("cuda", idx))   # its workspace may still be in flight
+                del old
+            h = _Handle(cfg, torch.device("cuda", idx))
         else:
             h.configure(cfg)
+        self._handles[key] = h            # most recently used last
         return h
 
     @staticmethod
@@ -304,16 +318,42 @@ class LMOptimizer(nn.Module):
 
     def forward(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         """Run the LM optimisation (reference: lm_optimizer.py:646-664)."""
+        if self.training and not self._warned_training and any(
+                torch.is_tensor(v) and v.requires_grad for v in data.values()):
+            # the training-time optimiser of siclib backpropagates through the solve; this path is an opaque C call
+            self._warned_training = True
+            logger.warning("geocalib_amd.LMOptimizer is inference-only: its outputs carry no autograd graph, so no "
+                           "gradient reaches the tensors of `data` that require one (INTEGRATION.md)")
         with torch.no_grad():
             data["latitude_field"]            # KeyError like get_trivial_estimation (lm_optimizer.py:31)
             self.setup_optimization_and_priors(data, shared_intrinsics=self.shared_intrinsics)
             camera_opt, gravity_opt, infos = self.calibrate_fields(data)
         return {"camera": camera_opt, "gravity": gravity_opt, **infos}
 
+    _MAX_CALL = 65535      # images per C call (grid.y of the sweep)
+
+    def _calibrate_chunked(self, data: Dict[str, torch.Tensor], B: int):
+        """Batches beyond 65 535 images: independent images are solved in slices of one C call each.  The device
+        early stop is per call, as it is per shard in parallel.calibrate_sharded."""
+        if self.shared_intrinsics:
+            raise ValueError(f"a shared-intrinsics batch is limited to {self._MAX_CALL} frames per call")
+        per_image = ("up_field", "latitude_field", "up_confidence", "latitude_confidence", "prior_focal",
+                     "prior_gravity", "prior_dist")
+        cams, gravs, infos, raws = [], [], [], []
+        for lo in range(0, B, self._MAX_CALL):
+            part = {k: (v[lo:lo + self._MAX_CALL] if k in per_image else v) for k, v in data.items()}
+            c, g, i = self.calibrate_fields(part)
+            cams.append(c._data); gravs.append(g._data); infos.append(i); raws.append(self._last_raw)
+        self._last_raw = tuple(torch.cat([r[j] for r in raws]) for j in range(3))
+        info = {k: torch.cat([i[k] for i in infos]) for k in infos[0]}
+        return self.camera_model(torch.cat(cams)), _unit_gravity(torch.cat(gravs)), info
+
     def calibrate_fields(self, data: Dict[str, torch.Tensor]) -> Tuple[BaseCamera, Gravity, Dict[str, torch.Tensor]]:
         """get_trivial_estimation + optimize in ONE C call (gclm_calibrate): the initial estimate is built
         on the device from (H, W) and the priors, so no host-side tensor op precedes the kernels."""
         up, lat, upc, latc, (B, H, W) = self._fields(data)
+        if B > self._MAX_CALL:
+            return self._calibrate_chunked(data, B)
         device = lat.device
         h = self._handle(device)
 

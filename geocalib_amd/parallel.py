@@ -48,21 +48,67 @@ def unpack_rows(rows: torch.Tensor):
     return rows[:, :8], rows[:, 8:11], rows[:, 11:11 + _lib.INFO_STRIDE]
 
 
-def all_gather_rows(rows: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+class CollectiveTimer:
+    """Device time spent inside the collectives of the N>1 paths: an event pair on the current stream around every
+    collective call (torch's nccl collectives run on their own stream, but a blocking call makes the current stream
+    wait for them, so the pair brackets the exchange as the solve sees it).  Read with total_ms() after a device
+    synchronisation; bench.py reports it as `collective_ms` so that a scaling curve can be attributed."""
+
+    def __init__(self):
+        self.pairs, self.calls = [], 0
+
+    def __call__(self, fn, device):
+        if device.type != "cuda":
+            self.calls += 1
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(device))
+        out = fn()
+        e1.record(torch.cuda.current_stream(device))
+        self.pairs.append((e0, e1))
+        self.calls += 1
+        return out
+
+    def total_ms(self) -> float:
+        ms = sum(a.elapsed_time(b) for a, b in self.pairs)
+        self.pairs = []
+        return ms
+
+
+class GatherPlan:
+    """Send / receive buffers of the result all-gather, allocated ONCE for a (n_total, world, device): nothing is
+    allocated inside a timed loop, and the padded send buffer is zeroed once."""
+
+    def __init__(self, n_total: int, world: int, device, dtype=torch.float32):
+        self.n_total, self.world = n_total, world
+        self.cap = (n_total + world - 1) // world
+        self.buf = torch.zeros((self.cap, ROW), dtype=dtype, device=device)
+        self.out = torch.empty((world * self.cap, ROW), dtype=dtype, device=device)
+        self.host = None          # gloo test rigs only
+
+
+def all_gather_rows(rows: torch.Tensor, n_total: int, group=None, plan: GatherPlan = None,
+                    timer: CollectiveTimer = None) -> torch.Tensor:
     """ONE all-gather of the per-image result rows of every rank -> (n_total, ROW), rank order.
     Shards may differ by one row: rows are padded to the largest shard for the collective."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    cap = (n_total + world - 1) // world
-    buf = rows.new_zeros((cap, rows.shape[1]))
+    if plan is None or plan.n_total != n_total or plan.world != world or plan.buf.device != rows.device:
+        plan = GatherPlan(n_total, world, rows.device, rows.dtype)
+    cap, buf, out = plan.cap, plan.buf, plan.out
     buf[: rows.shape[0]] = rows
-    out = rows.new_empty((world * cap, rows.shape[1]))
-    if rows.is_cuda and dist.get_backend(group) == "gloo":     # test rigs: gloo has no device collectives
-        host = out.cpu()
-        dist.all_gather_into_tensor(host, buf.cpu(), group=group)
-        out.copy_(host)
-    else:
-        dist.all_gather_into_tensor(out, buf, group=group)
+
+    def exchange():
+        if rows.is_cuda and dist.get_backend(group) == "gloo":     # test rigs: gloo has no device collectives
+            host = out.cpu()
+            dist.all_gather_into_tensor(host, buf.cpu(), group=group)
+            out.copy_(host)
+        else:
+            dist.all_gather_into_tensor(out, buf, group=group)
+
+    timer(exchange, rows.device) if timer is not None else exchange()
+    if n_total == world * cap:
+        return out                                   # equal shards: the receive buffer IS the result
     parts = []
     for r in range(world):
         lo, hi = shard_range(n_total, r, world)
@@ -138,19 +184,27 @@ def infos_from_rows(opt: LMOptimizer, rows: torch.Tensor, has_up: bool) -> Dict[
 
 
 def calibrate_sharded(opt: LMOptimizer, local_data: Dict[str, torch.Tensor], n_total: int,
-                      group=None, comm: "RcclComm" = None) -> Dict[str, torch.Tensor]:
+                      group=None, comm: "RcclComm" = None, plan: GatherPlan = None,
+                      timer: CollectiveTimer = None) -> Dict[str, torch.Tensor]:
     """Solve this rank's shard (independent intrinsics) and all-gather everybody's results.
 
     `local_data` holds the fields of the images [shard_range(n_total, rank, world)) of the global
-    batch; the returned dict covers all `n_total` images on every rank."""
+    batch; the returned dict covers all `n_total` images on every rank.  `plan` (GatherPlan) keeps the exchange
+    buffers across calls, `timer` (CollectiveTimer) accumulates the device time of the collective."""
     assert not opt.shared_intrinsics, "use SharedIntrinsicsSplit for shared intrinsics"
+    if opt.conf.early_stop and (comm is not None and comm.nranks > 1 or collectives_on(group)):
+        # the reference's early stop is ONE decision over the whole batch (lm_optimizer.py:90-92, 619); each rank
+        # would take it over its own shard and the gathered result would depend on the world size (SURVEY 8-B quirk 3)
+        raise ValueError("calibrate_sharded needs early_stop=False (a fixed number of steps): the batch-global early "
+                         "stop is not shard-invariant")
     out = opt(local_data)
     rows = pack_rows(*opt._last_raw)
     if comm is not None and comm.nranks > 1:       # direct RCCL route (equal shards)
         assert n_total % comm.nranks == 0, "the direct RCCL route expects equal shards"
-        return infos_from_rows(opt, comm.all_gather(rows), "up_field" in local_data)
+        gathered = timer(lambda: comm.all_gather(rows), rows.device) if timer is not None else comm.all_gather(rows)
+        return infos_from_rows(opt, gathered, "up_field" in local_data)
     if collectives_on(group):
-        rows = all_gather_rows(rows, n_total, group)
+        rows = all_gather_rows(rows, n_total, group, plan, timer)
         return infos_from_rows(opt, rows, "up_field" in local_data)
     return out
 
@@ -163,10 +217,12 @@ class SharedIntrinsicsSplit:
     (gclm_shared_reduce) -> ONE all-reduce(sum) of (num_groups, 16) floats -> solve + update
     (gclm_shared_apply)."""
 
-    def __init__(self, opt: LMOptimizer, num_groups: int, group=None, comm: "RcclComm" = None):
+    def __init__(self, opt: LMOptimizer, num_groups: int, group=None, comm: "RcclComm" = None,
+                 timer: CollectiveTimer = None):
         assert opt.shared_intrinsics, "optimizer must be configured with shared_intrinsics=True"
         assert not opt.conf.early_stop, "split shared intrinsics runs a fixed number of steps"
-        self.opt, self.num_groups, self.group, self.comm = opt, num_groups, group, comm
+        self.opt, self.num_groups, self.group, self.comm, self.timer = opt, num_groups, group, comm, timer
+        self._partials = None       # (num_groups, 32) exchange buffer, kept across calls
 
     def __call__(self, local_data: Dict[str, torch.Tensor], group_of_frame: torch.Tensor):
         opt, lib = self.opt, _lib.load()
@@ -179,9 +235,22 @@ class SharedIntrinsicsSplit:
             cam = _dev_f32(cam0._data, "camera").clone()
             grav = _dev_f32(grav0._data, "gravity").clone()
             gof = group_of_frame.to(device=dev, dtype=torch.int32).contiguous()
-            partials = torch.zeros((self.num_groups, _lib.SHARED_PARTIAL_STRIDE), dtype=torch.float32, device=dev)
+            if self._partials is None or self._partials.device != dev:
+                self._partials = torch.zeros((self.num_groups, _lib.SHARED_PARTIAL_STRIDE), dtype=torch.float32, device=dev)
+            partials = self._partials
             info = torch.empty((B, _lib.INFO_STRIDE), dtype=torch.float32, device=dev)
             multi = collectives_on(self.group)
+
+            def exchange():
+                if self.comm is not None:
+                    self.comm.all_reduce_sum_(partials)
+                elif multi and dist.get_backend(self.group) == "gloo":   # test rigs only
+                    host = partials.cpu()
+                    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                    partials.copy_(host)
+                elif multi:
+                    dist.all_reduce(partials, op=dist.ReduceOp.SUM, group=self.group)
+
             with torch.cuda.device(dev):
                 s = torch.cuda.current_stream(dev).cuda_stream
                 P = opt._ptr
@@ -190,14 +259,8 @@ class SharedIntrinsicsSplit:
                            "gclm_shared_begin")
                 for step in range(opt.num_steps):
                     _lib.check(lib.gclm_shared_reduce(h.ptr, step, partials.data_ptr(), s), h.ptr, "gclm_shared_reduce")
-                    if self.comm is not None:
-                        self.comm.all_reduce_sum_(partials)
-                    elif multi and dist.get_backend(self.group) == "gloo":   # test rigs only
-                        host = partials.cpu()
-                        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
-                        partials.copy_(host)
-                    elif multi:
-                        dist.all_reduce(partials, op=dist.ReduceOp.SUM, group=self.group)
+                    if self.comm is not None or multi:
+                        self.timer(exchange, dev) if self.timer is not None else exchange()
                     _lib.check(lib.gclm_shared_apply(h.ptr, step, partials.data_ptr(), s), h.ptr, "gclm_shared_apply")
                 _lib.check(lib.gclm_shared_finish(h.ptr, info.data_ptr(), s), h.ptr, "gclm_shared_finish")
         out = {"camera": cam0.__class__(cam), "gravity": Gravity(grav)}
@@ -205,5 +268,5 @@ class SharedIntrinsicsSplit:
         return out
 
 
-__all__ = ["shard_range", "pack_rows", "unpack_rows", "all_gather_rows", "calibrate_sharded",
-           "SharedIntrinsicsSplit", "RcclComm", "ROW", "BaseCamera"]
+__all__ = ["shard_range", "pack_rows", "unpack_rows", "all_gather_rows", "calibrate_sharded", "GatherPlan",
+           "CollectiveTimer", "SharedIntrinsicsSplit", "RcclComm", "ROW", "BaseCamera"]

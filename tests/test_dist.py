@@ -49,6 +49,37 @@ def _gather_worker(rank, world, n_total):
     assert cam.shape[1] == 8 and grav.shape[1] == 3 and info.shape[1] == 48
 
 
+def _gather_plan_worker(rank, world, n_total):
+    """The bench's N>1 loop: exchange buffers allocated once (GatherPlan), the collective timed (CollectiveTimer)."""
+    from geocalib_amd.parallel import ROW, CollectiveTimer, GatherPlan, all_gather_rows, shard_range
+    plan, timer = GatherPlan(n_total, world, torch.device("cpu")), CollectiveTimer()
+    buf_ptr, out_ptr = plan.buf.data_ptr(), plan.out.data_ptr()
+    lo, hi = shard_range(n_total, rank, world)
+    for it in range(3):
+        rows = (torch.arange(lo, hi, dtype=torch.float32)[:, None] + it) * torch.ones(1, ROW)
+        full = all_gather_rows(rows, n_total, plan=plan, timer=timer)
+        assert torch.equal(full[:, 0], torch.arange(n_total, dtype=torch.float32) + it)
+    assert timer.calls == 3 and (plan.buf.data_ptr(), plan.out.data_ptr()) == (buf_ptr, out_ptr)
+
+
+def test_gather_plan_reuses_its_buffers_world2():
+    _run(_gather_plan_worker, 2, 8)
+    _run(_gather_plan_worker, 2, 7)
+
+
+def _early_stop_worker(rank, world):
+    """calibrate_sharded refuses the batch-global early stop (not shard-invariant) before touching any tensor."""
+    import pytest
+    from geocalib_amd import LMOptimizer
+    from geocalib_amd.parallel import calibrate_sharded
+    with pytest.raises(ValueError, match="early_stop=False"):
+        calibrate_sharded(LMOptimizer({"camera_model": "pinhole"}), {}, 8)
+
+
+def test_calibrate_sharded_refuses_early_stop_world2():
+    _run(_early_stop_worker, 2)
+
+
 def test_shard_ranges_cover_batch():
     from geocalib_amd.parallel import shard_range
     for n in (0, 1, 7, 8, 1024, 8191):

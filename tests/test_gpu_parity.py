@@ -365,8 +365,9 @@ def test_full_size_batch_properties(dev, oracle, model):
     compare_result({k: v[idx] for k, v in a.items()}, ref, TOL, f"B1024/{model}")
 
 
+@pytest.mark.parametrize("split", ["interleaved", "empty_rank"])
 @pytest.mark.parametrize("model", HIP_MODELS)
-def test_split_protocol_two_virtual_ranks(dev, model):
+def test_split_protocol_two_virtual_ranks(dev, model, split):
     """BASELINE configs[4] protocol on ONE device: the frames of every group are dealt to two handles
     ("ranks"); per LM step both reduce their local Schur partials, the partial buffers are summed (what the
     RCCL all-reduce does), both apply.  Must equal the single-handle shared-intrinsics solve."""
@@ -379,7 +380,12 @@ def test_split_protocol_two_virtual_ranks(dev, model):
     frames = torch.arange(G * gs, device=dev)
     ranks = []
     for r in range(2):
-        sel = frames[(frames % gs) // (gs // 2) == r]                 # rank r: frames [r*gs/2, (r+1)*gs/2) of each group
+        if split == "interleaved":
+            sel = frames[(frames % gs) // (gs // 2) == r]             # rank r: frames [r*gs/2, (r+1)*gs/2) of each group
+            gof = (torch.arange(sel.numel(), device=dev, dtype=torch.int32) // (gs // 2)).contiguous()
+        else:                                                         # rank 1 holds NO frame: it only joins the all-reduce
+            sel = frames if r == 0 else frames[:0]
+            gof = (sel // gs).to(torch.int32).contiguous()
         local = {k: v[sel].contiguous() for k, v in data.items()}
         opt = LMOptimizer(conf).eval()
         cam0, grav0 = get_trivial_estimation(local, opt.camera_model)
@@ -387,10 +393,13 @@ def test_split_protocol_two_virtual_ranks(dev, model):
         up, lat, upc, latc, (B, _, _) = opt._fields(local)
         h = opt._handle(dev)
         st = dict(opt=opt, h=h, sel=sel, cam=cam0._data.clone(), grav=grav0._data.clone(), keep=(up, lat, upc, latc),
-                  gof=(torch.arange(B, device=dev, dtype=torch.int32) // (gs // 2)).contiguous(),
+                  gof=gof if gof.numel() else torch.zeros(1, device=dev, dtype=torch.int32),
                   part=torch.zeros((G, _lib.SHARED_PARTIAL_STRIDE), device=dev), info=torch.empty((B, _lib.INFO_STRIDE), device=dev))
-        _lib.check(lib.gclm_shared_begin(h.ptr, up.data_ptr(), lat.data_ptr(), upc.data_ptr(), latc.data_ptr(), B, H, W,
-                                         st["cam"].data_ptr(), st["grav"].data_ptr(), st["gof"].data_ptr(), G, None), h.ptr)
+        keep_alive = torch.zeros(16, device=dev)                     # an empty tensor has a null data_ptr
+        ptr = lambda t: t.data_ptr() if t.numel() else keep_alive.data_ptr()  # noqa: E731
+        st["keep_alive"] = keep_alive
+        _lib.check(lib.gclm_shared_begin(h.ptr, ptr(up), ptr(lat), ptr(upc), ptr(latc), B, H, W,
+                                         ptr(st["cam"]), ptr(st["grav"]), st["gof"].data_ptr(), G, None), h.ptr)
         ranks.append(st)
     for step in range(conf["num_steps"]):
         for st in ranks:
@@ -400,7 +409,7 @@ def test_split_protocol_two_virtual_ranks(dev, model):
             st["part"].copy_(total)
             _lib.check(lib.gclm_shared_apply(st["h"].ptr, step, st["part"].data_ptr(), None), st["h"].ptr)
     for st in ranks:
-        _lib.check(lib.gclm_shared_finish(st["h"].ptr, st["info"].data_ptr(), None), st["h"].ptr)
+        _lib.check(lib.gclm_shared_finish(st["h"].ptr, st["info"].data_ptr() or st["keep_alive"].data_ptr(), None), st["h"].ptr)
     torch.cuda.synchronize()
     for st in ranks:
         sel = st["sel"].cpu().numpy()
@@ -408,6 +417,9 @@ def test_split_protocol_two_virtual_ranks(dev, model):
         assert np.abs(st["cam"].cpu().numpy()[:, 6] - single["camera"][sel, 6]).max() < 2e-6
         assert np.abs(st["grav"].cpu().numpy() - single["gravity"][sel]).max() < 2e-6
         assert np.allclose(st["info"][:, _lib.INFO["final_cost"]].cpu().numpy(), single["final_cost"][sel], rtol=1e-5)
+    if split == "empty_rank":       # rank 0 did everything: the protocol IS the single-device solve, bit for bit
+        assert np.array_equal(ranks[0]["cam"].cpu().numpy(), single["camera"])
+        assert np.array_equal(ranks[0]["grav"].cpu().numpy(), single["gravity"])
     # one focal per group
     f = single["camera"][:, 3].reshape(G, gs)
     assert np.abs(f / f[:, :1] - 1).max() < 1e-6
@@ -646,7 +658,12 @@ def test_bench_multi_rank_path_on_one_gpu(dev, extra):
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 128 and out["scaling"] == "weak"
     assert out["value"] > 0 and out["unit"] == "images/sec" and out["steps"] == 2
     assert out["check"]["median_focal_rel_err_vs_gt"] < 5e-3
-    assert "cpu_baseline" not in out and out["roofline"]["launches_timed"] == 2 * 21
+    assert "cpu_baseline" not in out and out["roofline"]["launches_timed"] == out["repeats"] * 2 * 21
+    # the N>1 line is attributable: ranks seen by the communicator, every rank's own step time, time in the collective
+    mg = out["multi_gpu"]
+    assert mg["ranks_seen"] == 2 and len(mg["per_rank_ms"]) == 2 and all(t > 0 for t in mg["per_rank_ms"])
+    assert mg["collective_ms"] >= 0 and mg["collectives_per_step"] == (20 if extra else 1)
+    assert len(out["ms_per_step_repeats"]) == out["repeats"] == 3
 
 
 @pytest.mark.gpu
@@ -766,6 +783,8 @@ def test_bench_collectives_through_rccl_with_one_rank(dev, extra):
     assert len(lines) == 1, lines                   # ONE JSON line on stdout, no RCCL banner
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["global_batch"] == 64
+    assert out["multi_gpu"]["ranks_seen"] == 1 and out["multi_gpu"]["backend"] == "nccl"
+    assert out["multi_gpu"]["collective_ms"] > 0          # the collective really went through RCCL on the stream
 
 
 @pytest.mark.gpu
@@ -912,3 +931,134 @@ def test_huber_and_scaled_loss_functions(dev):
         assert torch.allclose(loss.double().cpu(), ref_loss, rtol=2e-6, atol=1e-12)
         assert torch.allclose(d1.double().cpu(), ref_d1, rtol=2e-6)
         assert torch.allclose(d2.double().cpu(), ref_d2, rtol=5e-6, atol=1e-12)
+
+
+# ------------------------------------------------------------------ degenerate inputs, limits, streams (through gclm_solve)
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", HIP_MODELS)
+def test_bad_images_are_contained(dev, model):
+    """A NaN pixel, an image without any confidence and a healthy image in ONE batch.  The reference zeroes the step
+    of the WHOLE batch when any Cholesky fails (lm_optimizer.py:129-133: one poisoned image stalls everybody); here
+    the failure is contained: the poisoned image takes zero steps and counts them in `step_failures`, its
+    neighbours are bit-identical to a clean run."""
+    data, _, _ = synth_device(model, 4, 96, 128, dev, seed=3)
+    conf = {"camera_model": model, "num_steps": 20, "early_stop": False}
+    clean = run_dev(conf, data)
+    bad = {k: v.clone() for k, v in data.items()}
+    bad["latitude_field"][1, 0, 5, 7] = float("nan")                   # image 1: NaN -> its Hessian is NaN -> not PD
+    bad["up_confidence"][2] = 0                                        # image 2: no information at all
+    bad["latitude_confidence"][2] = 0
+    out = run_dev(conf, bad)
+    for k in ("camera", "gravity", "final_cost", "covariance", "stop_at"):
+        if k == "stop_at":
+            continue                                                   # batch-global by definition (:619-620)
+        assert np.array_equal(out[k][[0, 3]], clean[k][[0, 3]]), f"{k}: a healthy image changed"
+    assert out["step_failures"][1] == 20 and out["step_failures"][[0, 2, 3]].max() == 0
+    init = run_dev({**conf, "num_steps": 0}, data)
+    assert np.array_equal(out["camera"][1], init["camera"][1]) and np.array_equal(out["gravity"][1], init["gravity"][1])
+    # zero confidence: H = G = 0, damping floor 1e-6 (:123-126) -> zero step, no failure, finite estimate
+    assert np.array_equal(out["camera"][2], init["camera"][2]) and np.isfinite(out["gravity"][2]).all()
+    assert out["final_cost"][2] == 0
+
+
+def run_dev(conf, data, training=False):
+    from geocalib_amd import LMOptimizer
+    opt = LMOptimizer(dict(conf))
+    out = (opt.train() if training else opt.eval())(data)
+    torch.cuda.synchronize()
+    return to_np(out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["simple_radial", "radial"])
+def test_prior_dist_against_oracle(dev, oracle, model):
+    """`prior_dist` fixes the distortion (lm_optimizer.py:334-336): the reference cannot run it batched
+    (camera.py:74-92 raises), so the oracle is the yardstick."""
+    inp = np.load(os.path.join(GOLDEN, f"inputs_{model}.npz"))
+    data = {k: inp[k] for k in ("up_field", "latitude_field", "up_confidence", "latitude_confidence")}
+    nd = 2 if model == "radial" else 1
+    data["prior_dist"] = inp["gt_camera"][:, 6:6 + nd].copy()
+    conf = {"camera_model": model, "num_steps": 20, "early_stop": False}
+    ref = oracle.solve(data, conf, precision="f32")
+    out = run(conf, data, dev)
+    compare_result(out, ref, TOL, f"prior_dist/{model}")
+    assert np.array_equal(out["camera"][:, 6:6 + nd], data["prior_dist"])      # untouched
+    assert out["covariance"].shape[1:] == (3, 3)                                # only (roll, pitch, focal) are free
+    free = run(conf, {k: v for k, v in data.items() if k != "prior_dist"}, dev)
+    assert np.abs(free["camera"][:, 6] - out["camera"][:, 6]).max() > 1e-5      # and it does change the answer
+
+
+@pytest.mark.gpu
+def test_8192_images_in_one_call(dev, oracle):
+    """BASELINE configs[2]'s total (8192 pinhole images, 640x480, 20 iterations) as ONE call on one GPU: a slice
+    solved on its own gives the same bits (images are independent; what an 8-GPU shard computes), and a sample of
+    the device-generated images agrees with the oracle."""
+    from geocalib_amd import LMOptimizer
+    B, H, W = 8192, 480, 640
+    data, gtc, gtg = synth_device("pinhole", B, H, W, dev, seed=21)
+    opt = LMOptimizer({"camera_model": "pinhole", "num_steps": 20, "early_stop": False}).eval()
+    full = to_np(opt(data))
+    assert full["step_failures"].max() == 0 and np.isfinite(full["camera"]).all()
+    assert np.median(np.abs(full["camera"][:, 3] / gtc[:, 3].cpu().numpy() - 1)) < 1e-3
+    lo, hi = 5 * 1024, 6 * 1024                                         # rank 5's shard of an 8-GPU run
+    shard = to_np(opt({k: v[lo:hi] for k, v in data.items()}))
+    for k in ("camera", "gravity", "final_cost", "covariance"):
+        assert np.array_equal(shard[k], full[k][lo:hi]), k
+    sample = [0, 4097, 8191]
+    host = {k: v[sample].cpu().numpy() for k, v in data.items()}
+    ref = oracle.solve(host, {"camera_model": "pinhole", "num_steps": 20, "early_stop": False}, precision="f32")
+    compare_result({k: v[sample] for k, v in full.items()}, ref, TOL, "B8192/sample")
+    del data
+
+
+@pytest.mark.gpu
+def test_more_than_65535_images_are_chunked(dev):
+    """One C call takes at most 65 535 images (grid.y); LMOptimizer slices larger batches instead of raising."""
+    from geocalib_amd import LMOptimizer
+    B, H, W = 65535 + 9, 8, 16
+    data, gtc, _ = synth_device("pinhole", B, H, W, dev, seed=4)
+    opt = LMOptimizer({"camera_model": "pinhole", "num_steps": 5, "early_stop": False}).eval()
+    out = to_np(opt(data))
+    assert out["camera"].shape == (B, 8) and out["covariance"].shape == (B, 3, 3) and np.isfinite(out["camera"]).all()
+    tail = to_np(opt({k: v[65535:] for k, v in data.items()}))
+    head = to_np(opt({k: v[:100] for k, v in data.items()}))
+    assert np.allclose(out["camera"][65535:], tail["camera"], rtol=1e-6) and np.allclose(out["camera"][:100], head["camera"], rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_two_streams_do_not_share_a_workspace(dev):
+    """One optimiser driven from two torch streams at once (the CNN of batch k+1 overlapping the LM of batch k): a
+    gclm_handle owns the whole solve workspace, so every (device, stream) gets its own (include/gclm.h)."""
+    from geocalib_amd import LMOptimizer
+    conf = {"camera_model": "simple_radial", "num_steps": 20, "early_stop": False}
+    a, _, _ = synth_device("simple_radial", 192, 240, 320, dev, seed=8)
+    b, _, _ = synth_device("simple_radial", 192, 240, 320, dev, seed=9)
+    opt = LMOptimizer(conf).eval()
+    ra, rb = to_np(opt(a)), to_np(opt(b))                               # one after the other
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    torch.cuda.synchronize()
+    for _ in range(3):                                                  # overlapped, repeatedly
+        with torch.cuda.stream(s1):
+            oa = opt(a)
+        with torch.cuda.stream(s2):
+            ob = opt(b)
+        torch.cuda.synchronize()
+        oa, ob = to_np(oa), to_np(ob)
+        for k in ("camera", "gravity", "final_cost", "stop_at"):
+            assert np.array_equal(oa[k], ra[k]) and np.array_equal(ob[k], rb[k]), k
+    assert len(opt._handles) == 3                                       # default stream + the two side streams
+
+
+@pytest.mark.gpu
+def test_entry_points_leave_the_current_device_alone(dev):
+    """Every C entry point restores the caller's current HIP device (also gclm_destroy at garbage collection)."""
+    from geocalib_amd import LMOptimizer
+    data, _, _ = synth_device("pinhole", 2, 32, 48, dev, seed=1)
+    before = torch.cuda.current_device()
+    opt = LMOptimizer({"camera_model": "pinhole", "num_steps": 3}).eval()
+    opt(data)
+    del opt
+    import gc
+    gc.collect()
+    assert torch.cuda.current_device() == before
