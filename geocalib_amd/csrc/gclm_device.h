@@ -236,7 +236,10 @@ __device__ inline void update_image(const SolveCtx& c, int step, int b, const fl
             if (!(act[i] && act[j])) A[i][j] = i == j ? 1.f : 0.f;
         if (act[i]) A[i][i] += fmaxf(A[i][i] * s.lambda, 1e-6f); else d[i] = 0.f;
     }
-    if (!chol_solve<PM>(A, d)) {
+    bool ok = chol_solve<PM>(A, d);
+#pragma unroll
+    for (int i = 0; i < PM; ++i) ok = ok && fabsf(d[i]) <= 3.0e38f;      // a NaN / inf step (NaN gradient) is a failed step too
+    if (!ok) {
 #pragma unroll
         for (int i = 0; i < PM; ++i) d[i] = 0.f;     // zero step for THIS image (reference: whole batch)
         s.fails += 1.f;

@@ -329,7 +329,11 @@ __device__ inline void apply_shared_frame(const SolveCtx& c, int step, int b, co
         for (int i = 0; i < ni; ++i) { r0 -= Hf[0][2 + i] * dI[i]; r1 -= Hf[1][2 + i] * dI[i]; }
         dG[0] = Dinv[0][0] * r0 + Dinv[0][1] * r1;
         dG[1] = Dinv[1][0] * r0 + Dinv[1][1] * r1;
-    } else {
+        ok = fabsf(dG[0]) <= 3.0e38f && fabsf(dG[1]) <= 3.0e38f;        // NaN / inf: a failed step
+        for (int i = 0; i < ni; ++i) ok = ok && fabsf(dI[i]) <= 3.0e38f;
+        if (!ok) dG[0] = dG[1] = 0.f;
+    }
+    if (!ok) {
         for (int i = 0; i < kNI; ++i) dI[i] = 0.f;
         s.fails += 1.f;
     }

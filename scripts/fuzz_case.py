@@ -5,42 +5,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from oracle import synth, lm_oracle as oracle
-ALL_MODELS = ["pinhole", "simple_radial", "radial", "simple_divisional"]
+from conftest import fuzz_draws
 seed, want = int(sys.argv[1]), int(sys.argv[2])
-rng = np.random.default_rng(seed)
-for case in range(want + 1):
-    model = ALL_MODELS[rng.integers(0, int(sys.argv[3]) if len(sys.argv) > 3 else 3)]
-    H, W = int(rng.integers(24, 90)), int(rng.integers(24, 120))
-    if rng.random() < 0.1:
-        H, W = int(rng.integers(200, 300)), int(rng.integers(260, 340))
-    if rng.random() < 0.5:
-        W = W // 4 * 4
-    B = int(rng.integers(1, 6))
-    data, cams, gravs = synth.make_fields(int(rng.integers(0, 1 << 30)), range(B), model, H, W,
-                                          noise=float(rng.choice([0.0, 0.01, 0.03])))
-    conf = {"camera_model": model, "num_steps": int(rng.integers(1, 25)), "early_stop": bool(rng.random() < 0.5),
-            "use_spherical_manifold": bool(rng.random() < 0.7), "use_log_focal": bool(rng.random() < 0.7),
-            "fix_lambda": bool(rng.random() < 0.2), "lambda_": float(rng.choice([0.1, 0.01, 1.0])),
-            "up_loss_fn_scale": float(rng.choice([1e-2, 5e-2])), "lat_loss_fn_scale": float(rng.choice([1e-2, 3e-2]))}
-    if rng.random() < 0.15:
-        conf["loss_fn"] = "squared_loss"
-    if rng.random() < 0.15:
-        conf["init_conf"] = {"name": "heuristic"}
-    mode = rng.random()
-    if mode < 0.15:
-        data = {k: v for k, v in data.items() if "confidence" not in k}
-    elif mode < 0.25:
-        data = {k: data[k] for k in ("latitude_field", "latitude_confidence")}
-        conf.pop("init_conf", None)
-    elif mode < 0.35:
-        data["prior_gravity"] = gravs
-    elif mode < 0.45 and model == "pinhole":
-        data["prior_focal"] = cams[:, 3].copy()
-    if rng.random() < 0.2:
-        data["scales"] = np.array([rng.uniform(0.4, 1.0), rng.uniform(0.4, 1.0)], np.float32)
-    shared = rng.random() < 0.15 and model != "radial" and "prior_gravity" not in data and "prior_focal" not in data
-    if shared:
-        conf |= {"shared_intrinsics": True, "early_stop": False}
+for case, model, (H, W), B, data, conf, cams, gravs in fuzz_draws(seed, want + 1, int(sys.argv[3]) if len(sys.argv) > 3 else 4):
+    pass
 print(case, model, (H, W), B, conf, list(data.keys()))
 r32 = oracle.solve(data, conf, precision="f32")
 r64 = oracle.solve(data, conf, precision="f64")

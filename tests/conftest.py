@@ -116,3 +116,60 @@ def compare_result(out: dict, ref: dict, tol: dict, label: str = ""):
         for key in ("roll_uncertainty", "pitch_uncertainty", "gravity_uncertainty", "focal_uncertainty", "vfov_uncertainty"):
             if np.abs(ref[key]).max() > 0:
                 assert rel(out[key], ref[key]) < tol["unc"], f"{label}: {key} {rel(out[key], ref[key]):.2e}"
+
+
+ALL_MODELS = ("pinhole", "simple_radial", "radial", "simple_divisional")
+
+
+def fuzz_draws(seed: int, n_cases: int, n_models: int = 4):
+    """The seeded random configurations of the fuzz tests: yields (case, model, (H, W), B, data, conf, cams, gravs).
+    Shared by tests/test_gpu_parity.py::test_randomised_configurations_against_oracle, scripts/fuzz_case.py and
+    tests/golden/make_golden_div.py (which runs the REFERENCE on the simple_divisional draws), so that a
+    (seed, case) pair names the same inputs everywhere."""
+    from oracle import synth
+    rng = np.random.default_rng(seed)
+    for case in range(n_cases):
+        model = ALL_MODELS[rng.integers(0, n_models)]
+        H, W = int(rng.integers(24, 90)), int(rng.integers(24, 120))
+        if rng.random() < 0.1:                                      # many chunk records per image: striped reduction
+            H, W = int(rng.integers(200, 300)), int(rng.integers(260, 340))
+        if rng.random() < 0.5:
+            W = W // 4 * 4
+        B = int(rng.integers(1, 6))
+        data, cams, gravs = synth.make_fields(int(rng.integers(0, 1 << 30)), range(B), model, H, W,
+                                              noise=float(rng.choice([0.0, 0.01, 0.03])))
+        conf = {"camera_model": model, "num_steps": int(rng.integers(1, 25)), "early_stop": bool(rng.random() < 0.5),
+                "use_spherical_manifold": bool(rng.random() < 0.7), "use_log_focal": bool(rng.random() < 0.7),
+                "fix_lambda": bool(rng.random() < 0.2), "lambda_": float(rng.choice([0.1, 0.01, 1.0])),
+                "up_loss_fn_scale": float(rng.choice([1e-2, 5e-2])), "lat_loss_fn_scale": float(rng.choice([1e-2, 3e-2]))}
+        if rng.random() < 0.15:
+            conf["loss_fn"] = "squared_loss"
+        if rng.random() < 0.15:
+            conf["init_conf"] = {"name": "heuristic"}
+        mode = rng.random()
+        if mode < 0.15:
+            data = {k: v for k, v in data.items() if "confidence" not in k}
+        elif mode < 0.25:
+            data = {k: data[k] for k in ("latitude_field", "latitude_confidence")}
+            conf.pop("init_conf", None)
+        elif mode < 0.35:
+            data["prior_gravity"] = gravs
+        elif mode < 0.45 and model == "pinhole":
+            data["prior_focal"] = cams[:, 3].copy()
+        if rng.random() < 0.2:
+            data["scales"] = np.array([rng.uniform(0.4, 1.0), rng.uniform(0.4, 1.0)], np.float32)
+        shared = rng.random() < 0.15 and model != "radial" and "prior_gravity" not in data and "prior_focal" not in data
+        if shared:
+            conf |= {"shared_intrinsics": True, "early_stop": False}
+        yield case, model, (H, W), B, data, conf, cams, gravs
+
+
+def result_spread(a: dict, b: dict) -> np.ndarray:
+    """[focal rel, gravity abs, distortion abs, final-cost rel] distance of two result dicts (fuzz gates)."""
+    rel_f = np.abs(a["camera"][:, 2:4] / b["camera"][:, 2:4] - 1).max()
+    dg = np.abs(a["gravity"] - b["gravity"]).max()
+    dk = np.abs(a["camera"][:, 6:] - b["camera"][:, 6:]).max()
+    # noise-free draws end at costs ~1e-9 that are pure rounding: measure against the problem's own scale
+    floor = max(1e-7, 1e-3 * np.abs(b["initial_cost"]).max())
+    dc = np.abs(a["final_cost"] - b["final_cost"]).max() / max(np.abs(b["final_cost"]).max(), floor)
+    return np.array([rel_f, dg, dk, dc], np.float64)

@@ -1,0 +1,82 @@
+"""Reference goldens for `simple_divisional` on the draws of the seeded fuzz generator, WITH the reference's own
+sensitivity (build container only: needs /root/reference).
+
+    python tests/golden/make_golden_div.py
+
+Why: the reference's `SimpleDivisional` Jacobians (camera.py:789-942, flagged "unstable" at :913) cancel
+catastrophically in float32 for small |k| -- the k-column of the Hessian comes out 10-1000x too large and the estimate
+stalls wherever rounding happens to leave it.  In that regime NO float32 implementation reproduces another one, the
+reference included: scaling its input by (1 +- 2^-23) pixel by pixel (a 1-ulp perturbation) moves its answer by more
+than the parity gate.  So for every simple_divisional draw of the fuzz generator (tests/conftest.fuzz_draws) this script
+stores
+
+    <seed>/<case>/{camera, gravity, final_cost, initial_cost, stop_at}   the reference's float32 result (CPU, eval)
+    <seed>/<case>/spread   [focal rel, gravity abs, k abs, final-cost rel]: how far the reference moves under two
+                           independent 1-ulp input perturbations
+
+and the GPU fuzz test gates the HIP path against the REFERENCE where spread <= 1e-3 and only asks for a finite result
+where the reference itself is not reproducible.  `siclib` knobs (loss_fn, init_conf) are not options of the inference
+optimiser (geocalib/lm_optimizer.py:144-162): such draws are left to the oracle.  Seeds: 2024 (the suite's default,
+40 cases) and 11, 12 (the soak of VERDICT r01, 300 cases each)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import fuzz_draws, result_spread  # noqa: E402
+from oracle import ref_import  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SEEDS = {2024: 40, 11: 300, 12: 300}
+PER_PIXEL = ("up_field", "latitude_field", "up_confidence", "latitude_confidence")
+
+
+def run(ref, conf, data):
+    opt = ref.lm_optimizer.LMOptimizer(dict(conf)).eval()
+    with torch.no_grad():
+        out = opt({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in data.items()})
+    res = {k: (v._data if k in ("camera", "gravity") else v).numpy().copy() for k, v in out.items()
+           if k in ("camera", "gravity", "final_cost", "initial_cost", "stop_at")}
+    return res
+
+
+def perturbed(data, rng):
+    """Every per-pixel input scaled by (1 +- 2^-23): one unit in the last place."""
+    out = dict(data)
+    for k in PER_PIXEL:
+        if k in data:
+            sign = rng.integers(0, 2, data[k].shape).astype(np.float32) * 2 - 1
+            out[k] = (data[k] * (np.float32(1) + sign * np.float32(2.0 ** -23))).astype(np.float32)
+    return out
+
+
+def main():
+    ref = ref_import.load()
+    torch.set_num_threads(os.cpu_count())
+    gold, n, unstable = {}, 0, 0
+    for seed, cases in SEEDS.items():
+        for case, model, (H, W), B, data, conf, cams, gravs in fuzz_draws(seed, cases, 4):
+            if model != "simple_divisional" or "loss_fn" in conf or "init_conf" in conf:
+                continue
+            base = run(ref, conf, data)
+            rng = np.random.default_rng([seed, case, 99])
+            spread = np.zeros(4)
+            for _ in range(2):
+                spread = np.maximum(spread, result_spread(run(ref, conf, perturbed(data, rng)), base))
+            for k, v in base.items():
+                gold[f"{seed}/{case}/{k}"] = v
+            gold[f"{seed}/{case}/spread"] = spread
+            n += 1
+            unstable += spread.max() > 1e-3
+            print(f"seed {seed} case {case}: {H}x{W} B={B} steps {conf['num_steps']} k_gt {cams[:, 6].round(3)} "
+                  f"k_ref {base['camera'][:, 6].round(4)} spread {spread}", flush=True)
+    np.savez_compressed(os.path.join(HERE, "golden_div_fuzz.npz"), **gold)
+    print(f"{n} simple_divisional draws, {unstable} of them not reproducible by the reference itself (spread > 1e-3)")
+
+
+if __name__ == "__main__":
+    main()

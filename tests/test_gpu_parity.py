@@ -260,7 +260,7 @@ def test_hip_matches_oracle_shared16_eight_groups(dev, oracle, model):
         ref = oracle.solve(d, conf, precision="f32", num_threads=os.cpu_count())
         sub = {k: v[16 * i:16 * (i + 1)] for k, v in out.items()}
         compare_result(sub, ref, TOL, f"shared16x8/{model}/g{groups[i]}")
-        assert np.abs(sub["camera"][0, 3] / cams[0, 3] - 1) < 3e-3                    # and it is the ground truth
+        assert np.abs(sub["camera"][0, 3] / cams[0, 3] - 1) < 1e-2                    # and it is the ground truth
 
 
 def test_group_size_equals_independent_shared_solves(dev):
@@ -413,6 +413,8 @@ def test_split_protocol_two_virtual_ranks(dev, model, split):
     torch.cuda.synchronize()
     for st in ranks:
         sel = st["sel"].cpu().numpy()
+        if sel.size == 0:
+            continue
         assert np.abs(st["cam"].cpu().numpy()[:, 2:4] / single["camera"][sel, 2:4] - 1).max() < 2e-6
         assert np.abs(st["cam"].cpu().numpy()[:, 6] - single["camera"][sel, 6]).max() < 2e-6
         assert np.abs(st["grav"].cpu().numpy() - single["gravity"][sel]).max() < 2e-6
@@ -492,71 +494,41 @@ def test_rccl_c_abi_single_rank(dev):
 
 
 def test_randomised_configurations_against_oracle(dev, oracle):
-    """Seeded fuzz: random shapes (vector and scalar paths), batch sizes, camera models, conf knobs, missing
-    confidences / up field, priors and scales -- the HIP path against the oracle on identical inputs."""
-    from oracle import synth
-    rng = np.random.default_rng(int(os.environ.get("GCLM_FUZZ_SEED", "2024")))     # soak: GCLM_FUZZ_CASES=400
-    worst, undetermined = {}, 0
-    for case in range(int(os.environ.get("GCLM_FUZZ_CASES", "40"))):
-        model = ALL_MODELS[rng.integers(0, int(os.environ.get("GCLM_FUZZ_MODELS", "3")))]   # 4: + simple_divisional (soak only)
-        H, W = int(rng.integers(24, 90)), int(rng.integers(24, 120))
-        if rng.random() < 0.1:                                      # many chunk records per image: striped reduction
-            H, W = int(rng.integers(200, 300)), int(rng.integers(260, 340))
-        if rng.random() < 0.5:
-            W = W // 4 * 4
-        B = int(rng.integers(1, 6))
-        data, cams, gravs = synth.make_fields(int(rng.integers(0, 1 << 30)), range(B), model, H, W,
-                                              noise=float(rng.choice([0.0, 0.01, 0.03])))
-        conf = {"camera_model": model, "num_steps": int(rng.integers(1, 25)), "early_stop": bool(rng.random() < 0.5),
-                "use_spherical_manifold": bool(rng.random() < 0.7), "use_log_focal": bool(rng.random() < 0.7),
-                "fix_lambda": bool(rng.random() < 0.2), "lambda_": float(rng.choice([0.1, 0.01, 1.0])),
-                "up_loss_fn_scale": float(rng.choice([1e-2, 5e-2])), "lat_loss_fn_scale": float(rng.choice([1e-2, 3e-2]))}
-        if rng.random() < 0.15:
-            conf["loss_fn"] = "squared_loss"
-        if rng.random() < 0.15:
-            conf["init_conf"] = {"name": "heuristic"}
-        mode = rng.random()
-        if mode < 0.15:
-            data = {k: v for k, v in data.items() if "confidence" not in k}
-        elif mode < 0.25:
-            data = {k: data[k] for k in ("latitude_field", "latitude_confidence")}
-            conf.pop("init_conf", None)
-        elif mode < 0.35:
-            data["prior_gravity"] = gravs
-        elif mode < 0.45 and model == "pinhole":
-            data["prior_focal"] = cams[:, 3].copy()
-        if rng.random() < 0.2:
-            data["scales"] = np.array([rng.uniform(0.4, 1.0), rng.uniform(0.4, 1.0)], np.float32)
-        shared = rng.random() < 0.15 and model != "radial" and "prior_gravity" not in data and "prior_focal" not in data
-        if shared:
-            conf |= {"shared_intrinsics": True, "early_stop": False}
+    """Seeded fuzz: random shapes (vector and scalar paths), batch sizes, ALL FOUR camera models, conf knobs, missing
+    confidences / up field, priors and scales -- the HIP path against the oracle on identical inputs, and for
+    `simple_divisional` against the REFERENCE's own result on that draw (tests/golden/make_golden_div.py), gated by
+    the reference's own reproducibility: where a 1-ulp perturbation of its input moves the reference by more than
+    1e-3 (its float32 k-column cancels for small |k|, camera.py:913) the draw only has to stay finite."""
+    from conftest import fuzz_draws, result_spread
+    seed = int(os.environ.get("GCLM_FUZZ_SEED", "2024"))                             # soak: GCLM_FUZZ_CASES=300
+    n_cases, n_models = int(os.environ.get("GCLM_FUZZ_CASES", "40")), int(os.environ.get("GCLM_FUZZ_MODELS", "4"))
+    div_path = os.path.join(GOLDEN, "golden_div_fuzz.npz")
+    div = np.load(div_path) if n_models == 4 and os.path.exists(div_path) else None
+    worst, undetermined, against_reference = {}, 0, 0
+    for case, model, (H, W), B, data, conf, cams, gravs in fuzz_draws(seed, n_cases, n_models):
         ref = oracle.solve(data, conf, precision="f32")
         ref64 = oracle.solve(data, conf, precision="f64")
         out = run(conf, data, dev)
-
-        def spread(a, b):
-            rel_f = np.abs(a["camera"][:, 2:4] / b["camera"][:, 2:4] - 1).max()
-            dg = np.abs(a["gravity"] - b["gravity"]).max()
-            dk = np.abs(a["camera"][:, 6:] - b["camera"][:, 6:]).max()
-            # noise-free draws end at costs ~1e-9 that are pure rounding: measure against the problem's own scale
-            floor = max(1e-7, 1e-3 * np.abs(b["initial_cost"]).max())
-            dc = np.abs(a["final_cost"] - b["final_cost"]).max() / max(np.abs(b["final_cost"]).max(), floor)
-            return np.array([rel_f, dg, dk, dc], np.float64)
-
-        # unconverged / ill-conditioned draws (few steps, tiny images at the focal clamp, radial k2 on a sliver of an
-        # image, noise-free costs ~1e-8) amplify rounding chaotically: where the oracle itself moves by more than
-        # 1e-3 between float32 and float64 the draw only has to stay finite; elsewhere the gate is tight
-        # (plus what the oracle moves).
         assert np.array_equal(out["camera"][:, [0, 1, 4, 5]], ref["camera"][:, [0, 1, 4, 5]])
         assert all(np.isfinite(out[k]).all() for k in ("camera", "gravity", "final_cost"))
-        own = spread(ref, ref64)
+        # unconverged / ill-conditioned draws (few steps, tiny images at the focal clamp, radial k2 on a sliver of an
+        # image, noise-free costs ~1e-8) amplify rounding chaotically: where the yardstick itself moves by more than
+        # 1e-3 (oracle: float32 vs float64; reference: 1-ulp input perturbations) the draw only has to stay finite;
+        # elsewhere the gate is tight (plus what the yardstick moves).
+        yard, own = ref, result_spread(ref, ref64)
+        if div is not None and model == "simple_divisional" and f"{seed}/{case}/camera" in div.files:
+            yard = {k: div[f"{seed}/{case}/{k}"] for k in ("camera", "gravity", "final_cost", "initial_cost")}
+            own = div[f"{seed}/{case}/spread"]
+            against_reference += 1
         if own.max() > 1e-3:
             undetermined += 1
             continue
-        worst[case] = spread(out, ref)
+        worst[case] = result_spread(out, yard)
         tol = np.array([2e-3, 2e-3, 5e-3, 2e-3]) + 10.0 * own
         assert (worst[case] < tol).all(), (case, model, (H, W), B, conf, worst[case], tol)
-    assert undetermined <= (0.2 if os.environ.get("GCLM_FUZZ_MODELS", "3") == "3" else 0.5) * (case + 1), undetermined
+    assert undetermined <= (0.2 if n_models == 3 else 0.35) * n_cases, undetermined
+    if div is not None and seed in (2024, 11, 12):
+        assert against_reference >= 5, against_reference      # simple_divisional really was drawn and gated by the reference
     med = np.median(np.array(list(worst.values())), axis=0)
     assert med[0] < 2e-5 and med[1] < 2e-5 and med[3] < 2e-5, med
 
@@ -946,7 +918,7 @@ def test_bad_images_are_contained(dev, model):
     conf = {"camera_model": model, "num_steps": 20, "early_stop": False}
     clean = run_dev(conf, data)
     bad = {k: v.clone() for k, v in data.items()}
-    bad["latitude_field"][1, 0, 5, 7] = float("nan")                   # image 1: NaN -> its Hessian is NaN -> not PD
+    bad["latitude_field"][1, 0, 5, 7] = float("nan")                   # image 1: NaN gradient -> NaN step -> rejected
     bad["up_confidence"][2] = 0                                        # image 2: no information at all
     bad["latitude_confidence"][2] = 0
     out = run_dev(conf, bad)
@@ -984,7 +956,8 @@ def test_prior_dist_against_oracle(dev, oracle, model):
     out = run(conf, data, dev)
     compare_result(out, ref, TOL, f"prior_dist/{model}")
     assert np.array_equal(out["camera"][:, 6:6 + nd], data["prior_dist"])      # untouched
-    assert out["covariance"].shape[1:] == (3, 3)                                # only (roll, pitch, focal) are free
+    # like the reference (:335-344), the system keeps the distortion columns (only update_estimate skips them, :541-547)
+    assert out["covariance"].shape[1:] == (3 + nd, 3 + nd)
     free = run(conf, {k: v for k, v in data.items() if k != "prior_dist"}, dev)
     assert np.abs(free["camera"][:, 6] - out["camera"][:, 6]).max() > 1e-5      # and it does change the answer
 
