@@ -1,8 +1,8 @@
 """Perspective fields of a camera (host-side torch renderer).
 
 Forward model of the reference's geocalib/perspective_fields.py (get_up_field :47, get_latitude_field
-:185, get_perspective_field :278, get_horizon_line :18), written on the radial-model hooks of
-geocalib_amd.camera.  Used to render ground-truth / visualisation fields; the optimiser does NOT
+ :185, get_perspective_field :278), written on the radial-model hooks of
+geocalib_amd.camera.  Used to render ground-truth fields; the optimiser does NOT
 call this module -- residuals and Jacobians are evaluated per pixel in csrc/gclm_pass.hip.
 
 J_up_field / J_latitude_field / J_perspective_field (:84, :214, :323) return the per-pixel Jacobian fields
@@ -59,17 +59,6 @@ def get_perspective_field(camera: BaseCamera, gravity: Gravity, use_up: bool = T
     up = get_up_field(camera, gravity).permute(0, 3, 1, 2) if use_up else camera.new_zeros((B, 2, h, w))
     lat = get_latitude_field(camera, gravity).permute(0, 3, 1, 2) if use_latitude else camera.new_zeros((B, 1, h, w))
     return up, lat
-
-
-def get_horizon_line(camera: BaseCamera, gravity: Gravity, relative: bool = True) -> torch.Tensor:
-    """Left / right image-border intersections of the horizon (fractions of the height if relative)."""
-    camera = camera.unsqueeze(0) if len(camera.shape) == 0 else camera
-    gravity = gravity.unsqueeze(0) if len(gravity.shape) == 0 else gravity
-    mid = camera.K @ gravity.R @ camera.new_tensor([0, 0, 1])
-    mid = mid[:2] / mid[2]
-    t = torch.tan(gravity.roll)
-    horizon = camera.new_tensor([mid[1] + mid[0] * t, mid[1] - (camera.size[0] - mid[0]) * t])
-    return horizon / camera.size[1] if relative else horizon
 
 
 def _jacobian_fields(camera: BaseCamera, gravity: Gravity, spherical: bool, log_focal: bool, want_up: bool,

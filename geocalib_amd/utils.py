@@ -49,26 +49,3 @@ def print_calibration(results) -> None:
     print(f"Focal: {camera.f[0, 1].item():.1f} px (± {results['focal_uncertainty'].item():.1f} px)")
     if hasattr(camera, "dist"):
         print(f"Dist:    {camera.dist[0, :camera.num_dist_params()].tolist()}")
-
-
-def skew_symmetric(v: torch.Tensor) -> torch.Tensor:
-    """[v]_x of a (batched) 3-vector: (..., 3) -> (..., 3, 3)   (reference: geocalib/utils.py:217-229)."""
-    x, y, z = v.unbind(-1)
-    o = torch.zeros_like(x)
-    rows = [torch.stack(r, -1) for r in ((o, -z, y), (z, o, -x), (-y, x, o))]
-    return torch.stack(rows, -2)
-
-
-def pitch2rho(pitch: torch.Tensor, f: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
-    """Signed distance of the horizon from the principal point in image heights (geocalib/utils.py:282-284)."""
-    return f * torch.tan(pitch) / h
-
-
-def rho2pitch(rho: torch.Tensor, f: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
-    """Inverse of pitch2rho (geocalib/utils.py:287-289)."""
-    return torch.atan(h * rho / f)
-
-
-def get_device() -> str:
-    """"cuda" (the HIP device under PyTorch-ROCm) when one is present, else "cpu" (geocalib/utils.py:302-309)."""
-    return "cuda" if torch.cuda.is_available() else "cpu"

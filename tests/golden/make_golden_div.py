@@ -17,7 +17,7 @@ stores
 and the GPU fuzz test gates the HIP path against the REFERENCE where spread <= 1e-3 and only asks for a finite result
 where the reference itself is not reproducible.  `siclib` knobs (loss_fn, init_conf) are not options of the inference
 optimiser (geocalib/lm_optimizer.py:144-162): such draws are left to the oracle.  Seeds: 2024 (the suite's default,
-40 cases) and 11, 12 (the soak of VERDICT r01, 300 cases each)."""
+80 cases) and 11, 12 (the soak of VERDICT r01, 300 cases each)."""
 import os
 import sys
 
@@ -31,7 +31,7 @@ from conftest import fuzz_draws, result_spread  # noqa: E402
 from oracle import ref_import  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SEEDS = {2024: 40, 11: 300, 12: 300}
+SEEDS = {2024: 80, 11: 300, 12: 300}
 PER_PIXEL = ("up_field", "latitude_field", "up_confidence", "latitude_confidence")
 
 

@@ -501,7 +501,7 @@ def test_randomised_configurations_against_oracle(dev, oracle):
     1e-3 (its float32 k-column cancels for small |k|, camera.py:913) the draw only has to stay finite."""
     from conftest import fuzz_draws, result_spread
     seed = int(os.environ.get("GCLM_FUZZ_SEED", "2024"))                             # soak: GCLM_FUZZ_CASES=300
-    n_cases, n_models = int(os.environ.get("GCLM_FUZZ_CASES", "40")), int(os.environ.get("GCLM_FUZZ_MODELS", "4"))
+    n_cases, n_models = int(os.environ.get("GCLM_FUZZ_CASES", "80")), int(os.environ.get("GCLM_FUZZ_MODELS", "4"))
     div_path = os.path.join(GOLDEN, "golden_div_fuzz.npz")
     div = np.load(div_path) if n_models == 4 and os.path.exists(div_path) else None
     worst, undetermined, against_reference = {}, 0, 0
@@ -517,9 +517,12 @@ def test_randomised_configurations_against_oracle(dev, oracle):
         # elsewhere the gate is tight (plus what the yardstick moves).
         yard, own = ref, result_spread(ref, ref64)
         if div is not None and model == "simple_divisional" and f"{seed}/{case}/camera" in div.files:
+            # the reference's float32 result is the yardstick; it is only as sharp as the reference is reproducible
+            # (1-ulp input perturbations) and as its cancelling formulas are accurate in float32 at this draw (the
+            # same algorithm in float64 -- a different operation order moves a float32 implementation that far)
             yard = {k: div[f"{seed}/{case}/{k}"] for k in ("camera", "gravity", "final_cost", "initial_cost")}
-            own = div[f"{seed}/{case}/spread"]
-            against_reference += 1
+            own = np.maximum(div[f"{seed}/{case}/spread"], own)
+            against_reference += own.max() <= 1e-3
         if own.max() > 1e-3:
             undetermined += 1
             continue
@@ -528,7 +531,7 @@ def test_randomised_configurations_against_oracle(dev, oracle):
         assert (worst[case] < tol).all(), (case, model, (H, W), B, conf, worst[case], tol)
     assert undetermined <= (0.2 if n_models == 3 else 0.35) * n_cases, undetermined
     if div is not None and seed in (2024, 11, 12):
-        assert against_reference >= 5, against_reference      # simple_divisional really was drawn and gated by the reference
+        assert against_reference >= 5, against_reference      # simple_divisional really was drawn and TIGHTLY gated by the reference
     med = np.median(np.array(list(worst.values())), axis=0)
     assert med[0] < 2e-5 and med[1] < 2e-5 and med[3] < 2e-5, med
 
@@ -928,9 +931,10 @@ def test_bad_images_are_contained(dev, model):
         assert np.array_equal(out[k][[0, 3]], clean[k][[0, 3]]), f"{k}: a healthy image changed"
     assert out["step_failures"][1] == 20 and out["step_failures"][[0, 2, 3]].max() == 0
     init = run_dev({**conf, "num_steps": 0}, data)
-    assert np.array_equal(out["camera"][1], init["camera"][1]) and np.array_equal(out["gravity"][1], init["gravity"][1])
+    # a zero step still re-applies f <- exp(log f + 0) and the manifold retraction (as the reference does): rounding only
+    assert np.allclose(out["camera"][1], init["camera"][1], rtol=1e-5) and np.allclose(out["gravity"][1], init["gravity"][1], atol=1e-6)
     # zero confidence: H = G = 0, damping floor 1e-6 (:123-126) -> zero step, no failure, finite estimate
-    assert np.array_equal(out["camera"][2], init["camera"][2]) and np.isfinite(out["gravity"][2]).all()
+    assert np.allclose(out["camera"][2], init["camera"][2], rtol=1e-5) and np.isfinite(out["gravity"][2]).all()
     assert out["final_cost"][2] == 0
 
 

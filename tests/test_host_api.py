@@ -198,18 +198,6 @@ def test_trivial_estimation_and_plan():
     assert LMOptimizer({"camera_model": "radial"})._config().camera_model == 2
 
 
-def test_small_utils():
-    from geocalib_amd import utils as u
-    v = torch.tensor([[1.0, 2.0, 3.0]])
-    S = u.skew_symmetric(v)
-    assert torch.equal(S, -S.transpose(-1, -2)) and torch.allclose(S[0] @ v[0], torch.zeros(3))
-    w = torch.tensor([0.3, -0.2, 0.5])
-    assert torch.allclose(S[0] @ w, torch.linalg.cross(v[0], w))
-    p, f, h = torch.tensor([0.2, -0.4]), torch.tensor([400.0, 650.0]), torch.tensor([480.0, 480.0])
-    assert torch.allclose(u.rho2pitch(u.pitch2rho(p, f, h), f, h), p, atol=1e-6)
-    assert u.get_device() in ("cpu", "cuda")
-
-
 def test_loop_rules_against_the_reference():
     """update_lambda / early_stop / update_estimate (host forms) against the reference's (only where it is mounted)."""
     from oracle import ref_import
