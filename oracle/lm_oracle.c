@@ -977,6 +977,7 @@ int lm_oracle_system(const oracle_conf *cf, const oracle_data *d, const float *c
                      double *G /*B x MAXP*/, double *Hm /*B x MAXP x MAXP*/) {
     plan_t pl;
     make_plan(cf, d, &pl);
+    if (cf->num_threads > 0) omp_set_num_threads(cf->num_threads);
 #pragma omp parallel for schedule(dynamic, 1)
     for (int b = 0; b < d->B; ++b) {
         cam_t c = {cam8[b * 8], cam8[b * 8 + 1], cam8[b * 8 + 2], cam8[b * 8 + 3], cam8[b * 8 + 4], cam8[b * 8 + 5], cam8[b * 8 + 6], cam8[b * 8 + 7]};

@@ -67,6 +67,31 @@ def _lib(precision: str):
     return _libs[precision]
 
 
+def effective_cpus() -> int:
+    """CPUs this process may actually use: min(os.cpu_count(), scheduler affinity, cgroup CPU quota).  A GPU box shows
+    256 logical CPUs but grants a container 16 of them (cpu.max); 256 OpenMP threads inside that quota spend their
+    time being throttled (a 3 s test took 220 s)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:                      # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                quota, period = int(fq.read()), int(fp.read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def _f32(a):
     return None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float32))
 
@@ -82,7 +107,7 @@ def _pack(conf, data, training=False, num_threads=0):
               float(cf["rtol"]), int(cf["use_spherical_manifold"]), int(cf["use_log_focal"]),
               float(2 ** 20 if cf["loss_fn"] == "squared_loss" else cf["up_loss_fn_scale"]),
               float(2 ** 20 if cf["loss_fn"] == "squared_loss" else cf["lat_loss_fn_scale"]), int(training),
-              int(num_threads), int(cf["init_conf"]["name"] == "heuristic"))
+              int(num_threads) if num_threads > 0 else effective_cpus(), int(cf["init_conf"]["name"] == "heuristic"))
     keep = {k: _f32(data.get(k)) for k in ("up_field", "latitude_field", "up_confidence",
                                            "latitude_confidence", "scales", "prior_focal",
                                            "prior_gravity", "prior_dist")}

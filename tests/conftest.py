@@ -14,6 +14,13 @@ BENCH = {"num_steps": 20, "early_stop": False}
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # host-side thread pools sized to what the container may use (a GPU box shows 256 CPUs and grants 16)
+    try:
+        import torch
+        from oracle.lm_oracle import effective_cpus
+        torch.set_num_threads(effective_cpus())
+    except Exception:
+        pass
 
 
 def pytest_sessionstart(session):
