@@ -9,13 +9,17 @@
  * `d_*` are DEVICE pointers owned by the caller (torch-ROCm tensors); `stream` is a hipStream_t
  * passed as void*.  Calls are asynchronous on `stream` and never synchronise the device.
  * Return value: 0 = ok, negative = error (message via gclm_last_error).  No C++ exception crosses
- * this boundary.  A handle is not thread-safe: one handle per (device, stream).
- * Numerical failure (non positive-definite system) is NOT an error: the image takes a zero step,
- * like lm_optimizer.py:129-133 (there batch-global, here per image / per shared group).
- * Degenerate inputs stay contained to their image and never hang (scripts/degenerate_probe.py): an image with
- * all-zero confidences keeps its initial estimate and reports a non-finite covariance (the reference's
- * torch.inverse raises on the singular Hessian); a NaN in a field makes THAT image's outputs NaN (its steps count
- * as failures, the batch-global early stop then never fires) and leaves the other images of the batch untouched.
+ * this boundary.  A handle is not thread-safe and owns the whole solve workspace: one handle per (device, stream).
+ * Every entry point runs on the handle's device and restores the caller's current HIP device before it returns.
+ * Numerical failure (non positive-definite system, or a NaN / inf step) is NOT an error: the image takes a zero
+ * step and counts it in GCLM_INFO_STEP_FAILURES, like lm_optimizer.py:129-133 (there batch-global, here per image /
+ * per shared group).
+ * Degenerate inputs stay contained to their image and never hang (tests/test_gpu_parity.py::
+ * test_bad_images_are_contained): an image with all-zero confidences keeps its initial estimate and reports a
+ * non-finite covariance (the reference's torch.inverse raises on the singular Hessian); a NaN in a field makes every
+ * step of THAT image fail (it keeps its initial estimate, its costs are NaN, the batch-global early stop then never
+ * fires) and leaves the other images of the batch bit-identical to a clean run.
+ * One call takes at most 65 535 images (grid.y); geocalib_amd.LMOptimizer slices larger batches.
  */
 #ifndef GCLM_H
 #define GCLM_H
@@ -27,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GCLM_VERSION 100
+#define GCLM_VERSION 101
 
 /* camera_models of geocalib/camera.py:945-950 */
 enum gclm_camera_model {
@@ -59,7 +63,7 @@ enum gclm_info_slot {
     GCLM_INFO_VFOV_UNC = 11,
     GCLM_INFO_NPARAMS = 12,
     GCLM_INFO_LAMBDA = 13,
-    GCLM_INFO_STEP_FAILURES = 14,  /* number of LM steps whose Cholesky failed (zero step) */
+    GCLM_INFO_STEP_FAILURES = 14,  /* number of LM steps rejected: Cholesky failed or the step was NaN / inf (zero step) */
     GCLM_INFO_COV = 16             /* covariance, P x P row-major, up to 25 floats */
 };
 
@@ -86,6 +90,12 @@ typedef struct gclm_config {
     int32_t compute_uncertainty;     /* eval mode: estimate_uncertainty (:635-636) */
     int32_t heuristic_init;          /* gclm_calibrate only: siclib's get_heuristic_estimation instead of the trivial
                                         estimate (siclib/models/optimization/utils.py:27-82; needs the up field) */
+    int32_t host_poll_steps;         /* OPT-IN latency mode, 0 = off (the default: a solve never synchronises).  n > 0 with
+                                        early_stop: every n LM steps the host waits for the stream and reads the 128-byte
+                                        early-stop counters, and stops launching once the stop has fired -- the reference
+                                        syncs for this decision every step (torch.allclose, :90-92).  Same results; a
+                                        default-conf single-image solve drops from ~0.29 ms to ~0.17 ms, at the price of
+                                        host synchronisation inside the call.  Ignored by the split protocol. */
 } gclm_config;
 
 typedef struct gclm_handle gclm_handle;
