@@ -32,8 +32,7 @@ class GclmConfig(C.Structure):
                 ("use_log_focal", C.c_int32), ("up_loss_fn_scale", C.c_float),
                 ("lat_loss_fn_scale", C.c_float), ("estimate_gravity", C.c_int32),
                 ("estimate_focal", C.c_int32), ("estimate_dist", C.c_int32),
-                ("compute_uncertainty", C.c_int32), ("heuristic_init", C.c_int32),
-                ("host_poll_steps", C.c_int32)]
+                ("compute_uncertainty", C.c_int32), ("heuristic_init", C.c_int32)]
 
     def key(self):
         return tuple(getattr(self, f) for f, _ in self._fields_)

@@ -64,7 +64,6 @@ const char* validate(const gclm_config& c) {
     if (c.num_steps < 0 || c.num_steps > GCLM_MAX_STEPS) return "num_steps out of range [0, GCLM_MAX_STEPS]";
     if (!(c.up_loss_fn_scale > 0.f) || !(c.lat_loss_fn_scale > 0.f)) return "loss scales must be > 0";
     if (c.group_size < 0) return "group_size must be >= 0";
-    if (c.host_poll_steps < 0) return "host_poll_steps must be >= 0";
     if (c.shared_intrinsics && !(c.estimate_gravity && c.estimate_focal))
         return "shared_intrinsics requires gravity and focal to be estimated (lm_optimizer.py:350-383)";
     if (c.shared_intrinsics && c.camera_model != GCLM_PINHOLE && !c.estimate_dist)
@@ -335,18 +334,7 @@ static int run_solve(gclm_handle* h, const float* d_up, const float* d_lat, cons
 
     GCLM_HIP(h, launch_init(c, ia, s));
     const bool es = h->cfg.early_stop != 0;
-    const int poll = es ? h->cfg.host_poll_steps : 0;
     for (int step = 0; step < h->cfg.num_steps; ++step) {
-        if (poll > 0 && step >= 2 && step % poll == 0) {
-            // opt-in latency mode: ask the device whether the batch-global stop has fired (notclose[j] == 0 for some
-            // executed update j >= 1) instead of launching kernels that would all skip themselves
-            Ctrl host;
-            GCLM_HIP(h, hipMemcpyAsync(&host, c.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
-            GCLM_HIP(h, hipStreamSynchronize(s));
-            bool fired = false;
-            for (int j = 1; j < step && !fired; ++j) fired = host.notclose[j] == 0;
-            if (fired) break;
-        }
         const SweepArgs a = sweep_args(h, d_up, d_lat, d_up_conf, d_lat_conf, c.pb[step & 1], geo, true, es ? step : 0);
         if (int rc = timed_sweep(h, a, s)) return rc;
         if (!h->cfg.shared_intrinsics) {

@@ -166,9 +166,6 @@ class LMOptimizer(nn.Module):
         # knobs of the training-time optimiser (siclib/models/optimization/lm_optimizer.py:37-59)
         "loss_fn": "huber_loss",          # {"huber_loss", "squared_loss"}
         "init_conf": {"name": "trivial"},  # {"trivial", "heuristic"} (siclib/models/optimization/utils.py:16-82)
-        # extension, opt-in latency mode: every n LM steps the host waits for the stream, reads the early-stop counters
-        # and stops launching once the (device-side, batch-global) stop has fired.  0 = never synchronise (default)
-        "host_poll_steps": 0,
     }
 
     # squared_loss (siclib/models/optimization/losses.py:26) is the Huber loss with an unreachable threshold:
@@ -236,7 +233,6 @@ class LMOptimizer(nn.Module):
         init_name = c.init_conf["name"] if isinstance(c.init_conf, dict) else getattr(c.init_conf, "name", "trivial")
         assert init_name in ("trivial", "heuristic"), f"Unknown initialisation: {init_name}"
         cfg.heuristic_init = int(init_name == "heuristic")
-        cfg.host_poll_steps = int(c.host_poll_steps or 0)
         cfg.estimate_gravity = int(self.estimate_gravity)
         cfg.estimate_focal = int(self.estimate_focal)
         cfg.estimate_dist = int(self.estimate_dist)

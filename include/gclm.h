@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GCLM_VERSION 101
+#define GCLM_VERSION 100
 
 /* camera_models of geocalib/camera.py:945-950 */
 enum gclm_camera_model {
@@ -90,12 +90,6 @@ typedef struct gclm_config {
     int32_t compute_uncertainty;     /* eval mode: estimate_uncertainty (:635-636) */
     int32_t heuristic_init;          /* gclm_calibrate only: siclib's get_heuristic_estimation instead of the trivial
                                         estimate (siclib/models/optimization/utils.py:27-82; needs the up field) */
-    int32_t host_poll_steps;         /* OPT-IN latency mode, 0 = off (the default: a solve never synchronises).  n > 0 with
-                                        early_stop: every n LM steps the host waits for the stream and reads the 128-byte
-                                        early-stop counters, and stops launching once the stop has fired -- the reference
-                                        syncs for this decision every step (torch.allclose, :90-92).  Same results; a
-                                        default-conf single-image solve drops from ~0.29 ms to ~0.17 ms, at the price of
-                                        host synchronisation inside the call.  Ignored by the split protocol. */
 } gclm_config;
 
 typedef struct gclm_handle gclm_handle;

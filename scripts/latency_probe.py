@@ -9,7 +9,7 @@ rows = []
 for model in ("pinhole", "simple_radial"):
     for (B, H, W) in ((1, 320, 480), (1, 480, 640), (4, 480, 640), (16, 480, 640)):
         d, gtc, _ = synth_fields(model, B, H, W, dev, seed=1)
-        for conf in ({"num_steps": 20, "early_stop": False}, {}, {"host_poll_steps": 5}):
+        for conf in ({"num_steps": 20, "early_stop": False}, {}):
             opt = LMOptimizer({"camera_model": model, **conf}).eval()
             for _ in range(3): out = opt(d)
             torch.cuda.synchronize()
@@ -18,12 +18,11 @@ for model in ("pinhole", "simple_radial"):
                 t = time.perf_counter(); out = opt(d); torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
             ts.sort(); dt = ts[n // 2]
             rows.append({"camera_model": model, "batch": B, "height": H, "width": W,
-                         "conf": ("num_steps=20, early_stop=False" if "num_steps" in conf else
-                                  "default + host_poll_steps=5 (opt-in: the host reads the early-stop counters every 5 steps)" if conf
-                                  else "default (30 steps, early stop on the device, never synchronises)"),
+                         "conf": "num_steps=20, early_stop=False" if conf else "default (30 steps, early stop on the device)",
                          "median_us_per_solve": round(dt * 1e6, 1), "p10_us": round(ts[n // 10] * 1e6, 1),
                          "p90_us": round(ts[(9 * n) // 10] * 1e6, 1), "stop_at": out["stop_at"][0].item()})
-            print(f"{model:14s} B={B:3d} {W}x{H} conf={'bench20' if 'num_steps' in conf else 'default+poll5' if conf else 'default(early stop)'}: {dt*1e6:8.1f} us/solve  stop_at={out['stop_at'][0].item():.0f}", flush=True)
+            print(f"{model:14s} B={B:3d} {W}x{H} conf={'bench20' if conf else 'default(early stop)'}: {dt*1e6:8.1f} us/solve  stop_at={out['stop_at'][0].item():.0f}", flush=True)
 if "--json" in sys.argv:
+    os.makedirs(os.path.dirname(os.path.abspath(sys.argv[sys.argv.index("--json") + 1])), exist_ok=True)
     with open(sys.argv[sys.argv.index("--json") + 1], "w") as fh:
         json.dump({"what": "host wall time of LMOptimizer.forward + synchronize, median of 50", "rows": rows}, fh, indent=1)

@@ -47,7 +47,7 @@ def test_code_object_targets_gfx950():
 
 def test_default_config_matches_reference_defaults():
     lib = _lib.load()
-    assert lib.gclm_version() == 101
+    assert lib.gclm_version() == 100
     cfg = _lib.GclmConfig()
     assert lib.gclm_default_config(C.byref(cfg)) == 0
     # LMOptimizer.default_conf, lm_optimizer.py:144-162
@@ -56,7 +56,7 @@ def test_default_config_matches_reference_defaults():
     assert cfg.use_spherical_manifold == 1 and cfg.use_log_focal == 1
     assert cfg.up_loss_fn_scale == pytest.approx(1e-2) and cfg.lat_loss_fn_scale == pytest.approx(1e-2)
     assert cfg.estimate_gravity == cfg.estimate_focal == cfg.estimate_dist == cfg.compute_uncertainty == 1
-    assert cfg.heuristic_init == 0 and cfg.host_poll_steps == 0 and C.sizeof(_lib.GclmConfig) == 19 * 4
+    assert cfg.heuristic_init == 0 and C.sizeof(_lib.GclmConfig) == 18 * 4
 
 
 def test_create_rejects_bad_config_with_message():

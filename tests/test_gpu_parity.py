@@ -1045,17 +1045,3 @@ def test_entry_points_leave_the_current_device_alone(dev):
     import gc
     gc.collect()
     assert torch.cuda.current_device() == before
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("model", HIP_MODELS)
-def test_host_poll_latency_mode_gives_the_same_answer(dev, model):
-    """`host_poll_steps` (opt-in): the host reads the device's early-stop counters every n steps and stops launching
-    once the stop has fired -- same bits as the never-synchronising default, whatever n."""
-    data, _, _ = synth_device(model, 3, 120, 160, dev, seed=6)
-    base = run_dev({"camera_model": model}, data)
-    assert 2 <= base["stop_at"][0] < 30                                 # the early stop does fire on this input
-    for n in (1, 4, 7, 64):
-        out = run_dev({"camera_model": model, "host_poll_steps": n}, data)
-        for k in base:
-            assert np.array_equal(out[k], base[k], equal_nan=True), (n, k)
