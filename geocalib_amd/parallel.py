@@ -6,7 +6,7 @@ result rows (camera 8 + gravity 3 + infos 48 floats = 236 B/image) are exchanged
 all-gather.  The payload is KBs: latency-bound, so everything is packed into a single collective.
 
 Shared intrinsics with a group's frames split across ranks (BASELINE config 5): per LM step every
-rank reduces its frames to per-group Schur partials (16 floats/group, csrc/gclm_update.hip), ONE
+rank reduces its frames to per-group Schur partials (32 floats/group, csrc/gclm_update.hip), ONE
 all-reduce(sum) over all groups, then every rank solves the tiny Schur systems redundantly and
 updates its own frames.  The reference has no counterpart (its LM is single-process): parity is
 checked on the gathered results against the single-process oracle.
@@ -214,7 +214,7 @@ class SharedIntrinsicsSplit:
 
     Every rank holds `local_data` (its frames, sorted by group id) and `group_of_frame`
     (int32, non-decreasing, values in [0, num_groups)).  Per step: local sweep + Schur partials
-    (gclm_shared_reduce) -> ONE all-reduce(sum) of (num_groups, 16) floats -> solve + update
+    (gclm_shared_reduce) -> ONE all-reduce(sum) of (num_groups, 32) floats -> solve + update
     (gclm_shared_apply)."""
 
     def __init__(self, opt: LMOptimizer, num_groups: int, group=None, comm: "RcclComm" = None,

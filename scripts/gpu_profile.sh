@@ -17,7 +17,9 @@ echo "== bench $NAME ($EXTRA)"
 python $REPO/bench.py --steps 10 --warmup 2 --camera-model $MODEL $EXTRA > $OUT/bench_$NAME.json 2> $OUT/bench_$NAME.err
 tail -c 2500 $OUT/bench_$NAME.json
 echo "== kernel trace $NAME"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$NAME -o kt -- python $REPO/bench.py --steps 3 --warmup 1 --repeats 1 --cpu-sample 0 --camera-model $MODEL $EXTRA > $OUT/kt_$NAME.log 2>&1
+# the SAME command as the bench line (steps, warm-up, repeats), so that the two sweep averages are comparable: a short run
+# sweeps 2-3 % faster than a sustained one (power / clocks)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$NAME -o kt -- python $REPO/bench.py --steps 10 --warmup 2 --camera-model $MODEL $EXTRA --cpu-sample 0 > $OUT/kt_$NAME.log 2>&1
 find $OUT/kt_$NAME -name "*kernel_stats.csv" | head -1 | xargs -r head -8
 if [ "$PMC" = "1" ]; then
 echo "== pmc FETCH_SIZE"

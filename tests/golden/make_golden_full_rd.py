@@ -1,0 +1,54 @@
+"""Reference goldens for the two non-BASELINE camera models AT THE BASELINE IMAGE SIZE (640x480, 20 iterations).
+
+    python tests/golden/make_golden_full_rd.py        (build container only: needs /root/reference)
+
+`radial` (k1, k2; camera.py:663-786) and `simple_divisional` (camera.py:789-942), two seeded images each, run through
+the reference's own LMOptimizer (CPU float32, eval, no_grad).  For `simple_divisional` the reference's 1-ulp input
+sensitivity is stored too (see make_golden_div.py): the gate of the tests is [..] + 10 x spread.  Inputs are regenerated
+from the seed by the tests; only outputs and an input checksum are stored (golden_full_rd.npz)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import result_spread  # noqa: E402
+from oracle import ref_import, synth  # noqa: E402
+from make_golden_div import perturbed, run  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SEED, FULL = 1234, (480, 640)
+INDICES = {"radial": (0, 1), "simple_divisional": (2, 5)}
+BENCH = {"num_steps": 20, "early_stop": False}
+
+
+def main():
+    ref = ref_import.load()
+    torch.set_num_threads(os.cpu_count())
+    out = {}
+    for model, idx in INDICES.items():
+        data, cams, gravs = synth.make_fields(SEED, idx, model, *FULL)
+        conf = {"camera_model": model, **BENCH}
+        opt = ref.lm_optimizer.LMOptimizer(dict(conf)).eval()
+        with torch.no_grad():
+            res = opt({k: torch.from_numpy(v) for k, v in data.items()})
+        for k, v in res.items():
+            out[f"{model}/{k}"] = (v._data if k in ("camera", "gravity") else v).numpy().copy()
+        out[f"{model}/input_checksum"] = np.array([np.float64(np.asarray(v, np.float64).sum()) for _, v in sorted(data.items())])
+        out[f"{model}/gt_camera"], out[f"{model}/gt_gravity"] = cams, gravs
+        base = run(ref, conf, data)
+        rng = np.random.default_rng([SEED, 77])
+        spread = np.zeros(4)
+        for _ in range(2):
+            spread = np.maximum(spread, result_spread(run(ref, conf, perturbed(data, rng)), base))
+        out[f"{model}/spread"] = spread
+        print(model, "f", out[f"{model}/camera"][:, 2], "gt", cams[:, 2], "k", out[f"{model}/camera"][:, 6:8].ravel(), "gt", cams[:, 6:8].ravel(),
+              "1-ulp spread", spread, flush=True)
+    np.savez_compressed(os.path.join(HERE, "golden_full_rd.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()

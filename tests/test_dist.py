@@ -129,7 +129,7 @@ def _schur_worker(rank, world, setname, q):
     sysm = lm_oracle.system(data, init["camera"], init["gravity"], conf, precision="f64")
     Hs, Gs, lam = sysm["H"], sysm["G"], 0.1
     lo, hi = shard_range(B, rank, world)
-    # local Schur partials, layout of gclm_update.hip::shared_group_kernel (stride 32, 3x3 blocks)
+    # local Schur partials, layout of gclm_update.hip::shared_step_kernel (stride 32, 3x3 blocks)
     part = np.zeros(32)
     for b in range(lo, hi):
         Dinv = np.linalg.inv(_damped(Hs[b, :2, :2], lam))

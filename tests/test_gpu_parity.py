@@ -83,6 +83,25 @@ def test_hip_matches_reference_full_size(dev, model):
     assert np.array_equal(out["stop_at"], ref["stop_at"])
 
 
+@pytest.mark.parametrize("model,idx", [("radial", (0, 1)), ("simple_divisional", (2, 5))])
+def test_hip_matches_reference_full_size_other_models(dev, model, idx):
+    """The two non-BASELINE camera models at the BASELINE image size (640x480, 20 iterations) against the REFERENCE's own
+    result (tests/golden/make_golden_full_rd.py): north_star's 1e-4, plus 10 x the reference's own 1-ulp input
+    sensitivity on these images (2e-4 at most: both are in the regime where the reference reproduces itself)."""
+    from conftest import result_spread
+    from oracle import synth
+    g = np.load(os.path.join(GOLDEN, "golden_full_rd.npz"))
+    data, cams, gravs = synth.make_fields(1234, idx, model, 480, 640)
+    chk = np.array([np.float64(np.asarray(v, np.float64).sum()) for _, v in sorted(data.items())])
+    assert np.allclose(chk, g[f"{model}/input_checksum"], rtol=1e-9, atol=1e-3)
+    out = run({"camera_model": model, "num_steps": 20, "early_stop": False}, data, dev)
+    ref = {k.split("/", 1)[1]: g[k] for k in g.files if k.startswith(model + "/")}
+    d = result_spread(out, ref)
+    assert (d < 1e-4 + 10.0 * ref["spread"]).all(), (model, d, ref["spread"])
+    assert np.array_equal(out["stop_at"], ref["stop_at"]) or model == "simple_divisional"
+    assert np.abs(out["covariance"] - ref["covariance"]).max() / np.abs(ref["covariance"]).max() < 1e-3
+
+
 @pytest.mark.parametrize("variant", ["default", "bench"])
 def test_hip_matches_reference_cnn_fields(dev, variant, oracle):
     """BASELINE configs[0] restated: fields of the reference CNN (seeded random init) on the church image.

@@ -237,3 +237,21 @@ def test_oracle_matches_reference_divisional_fuzz_draws(oracle):
             assert (d < tol).all(), (seed, case, (H, W), B, conf, d, tol)
             checked += 1
     assert checked >= 10 and undefined >= 3, (checked, undefined)
+
+
+@pytest.mark.parametrize("model,idx", [("radial", (0, 1)), ("simple_divisional", (2, 5))])
+def test_oracle_matches_reference_full_size_other_models(oracle, model, idx):
+    """The two non-BASELINE camera models at the BASELINE image size (640x480, 20 iterations, two images each) against
+    the reference's own result (tests/golden/make_golden_full_rd.py); gate = 1e-4 + 10 x the reference's own 1-ulp
+    input sensitivity on these images."""
+    from conftest import result_spread
+    from oracle import synth
+    g = np.load(os.path.join(GOLDEN, "golden_full_rd.npz"))
+    data, cams, gravs = synth.make_fields(1234, idx, model, 480, 640)
+    chk = np.array([np.float64(np.asarray(v, np.float64).sum()) for _, v in sorted(data.items())])
+    assert np.allclose(chk, g[f"{model}/input_checksum"], rtol=1e-9, atol=1e-3), "regenerated inputs drifted"
+    out = oracle.solve(data, {"camera_model": model, "num_steps": 20, "early_stop": False}, precision="f32")
+    ref = {k.split("/", 1)[1]: g[k] for k in g.files if k.startswith(model + "/")}
+    d = result_spread(out, ref)
+    assert (d < 1e-4 + 10.0 * ref["spread"]).all(), (model, d, ref["spread"])
+    assert np.abs(out["camera"][:, 3] / cams[:, 3] - 1).max() < 5e-3          # and it is the ground truth
