@@ -9,7 +9,7 @@ for f in sorted(glob.glob(os.path.join(src, "bench_*.json"))):
     line = [l for l in open(f).read().splitlines() if l.startswith("{")]
     if not line:
         continue
-    name = os.path.basename(f)[len("bench_"):-len(".json")]
+    name = os.path.basename(f)[len("bench_"):-len(".json")]      # "traced_<name>": the line printed by the rocprofv3-traced process
     with open(os.path.join(dst, f"{tag}_bench_{name}.json"), "w") as fh:
         json.dump(json.loads(line[-1]), fh, indent=1)
     kept.append(f"{tag}_bench_{name}.json")

@@ -98,7 +98,9 @@ def test_hip_matches_reference_full_size_other_models(dev, model, idx):
     ref = {k.split("/", 1)[1]: g[k] for k in g.files if k.startswith(model + "/")}
     d = result_spread(out, ref)
     assert (d < 1e-4 + 10.0 * ref["spread"]).all(), (model, d, ref["spread"])
-    assert np.array_equal(out["stop_at"], ref["stop_at"]) or model == "simple_divisional"
+    # stop_at: the step at which every cost has stopped moving by 1e-8 -- these two models creep along a flat
+    # distortion valley, so the crossing is rounding noise: the same step or its neighbour
+    assert np.abs(out["stop_at"] - ref["stop_at"]).max() <= 1, (out["stop_at"], ref["stop_at"])
     assert np.abs(out["covariance"] - ref["covariance"]).max() / np.abs(ref["covariance"]).max() < 1e-3
 
 
