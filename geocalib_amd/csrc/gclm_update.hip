@@ -632,21 +632,49 @@ __global__ void pack_fields_kernel(const float* __restrict__ up_raw, const float
 // GeoCalib._post_process (extractor.py:51-69) brings the fields back to the input resolution with
 // F.interpolate(mode="bilinear", align_corners=False); one launch for any number of (h, w) planes.
 // Source index as in ATen (area_pixel_compute_source_index): src = max(0, (dst + 0.5) * in/out - 0.5).
-__global__ void upsample_bilinear_kernel(const float* __restrict__ src, int planes, int h, int w, int H, int W,
-                                         float* __restrict__ dst) {
+// VEC = 4: one thread produces four horizontally adjacent output pixels (ONE 16-byte non-temporal store: the output is
+// the traffic, it is written once and read by a later kernel) of a row whose vertical taps it computes once; the 2 x 2
+// source taps per pixel are L1 / L2 hits (neighbouring threads share them).  32-bit index arithmetic, rows walked with an
+// incremental (row, unit) counter instead of a division per pixel.  VEC = 1: any width / alignment.
+template <int VEC>
+__global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __restrict__ src, int planes, int h, int w,
+                                                                  int H, int W, float* __restrict__ dst) {
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
-    const size_t total = (size_t)planes * H * W;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int X = (int)(i % W), Y = (int)((i / W) % H);
-        const size_t p = i / ((size_t)W * H);
-        const float fy = fmaxf(((float)Y + 0.5f) * sy - 0.5f, 0.f), fx = fmaxf(((float)X + 0.5f) * sx - 0.5f, 0.f);
-        const int y0 = min((int)fy, h - 1), x0 = min((int)fx, w - 1);
-        const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
-        const float ly = fy - (float)y0, lx = fx - (float)x0;
-        const float* s = src + p * (size_t)h * w;
-        const float top = s[(size_t)y0 * w + x0] * (1.f - lx) + s[(size_t)y0 * w + x1] * lx;
-        const float bot = s[(size_t)y1 * w + x0] * (1.f - lx) + s[(size_t)y1 * w + x1] * lx;
-        dst[i] = top * (1.f - ly) + bot * ly;
+    const int Wu = W / VEC;                           // units per output row
+    const unsigned units = (unsigned)H * (unsigned)Wu;
+    const unsigned stride = gridDim.x * blockDim.x;
+    const int dY = (int)(stride / (unsigned)Wu), dXu = (int)(stride - (unsigned)dY * (unsigned)Wu);
+    for (int p = blockIdx.y; p < planes; p += gridDim.y) {
+        const float* s = src + (size_t)p * h * w;
+        float* d = dst + (size_t)p * H * W;
+        unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
+        int Y = (int)(q / (unsigned)Wu), Xu = (int)(q - (unsigned)Y * (unsigned)Wu);
+        for (; q < units; q += stride) {
+            const float fy = fmaxf(((float)Y + 0.5f) * sy - 0.5f, 0.f);
+            const int y0 = min((int)fy, h - 1), y1 = min(y0 + 1, h - 1);
+            const float ly = fy - (float)y0;
+            const float* r0 = s + y0 * w;
+            const float* r1 = s + y1 * w;
+            float o[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const int X = Xu * VEC + k;
+                const float fx = fmaxf(((float)X + 0.5f) * sx - 0.5f, 0.f);
+                const int x0 = min((int)fx, w - 1), x1 = min(x0 + 1, w - 1);
+                const float lx = fx - (float)x0;
+                const float top = r0[x0] * (1.f - lx) + r0[x1] * lx;
+                const float bot = r1[x0] * (1.f - lx) + r1[x1] * lx;
+                o[k] = top * (1.f - ly) + bot * ly;
+            }
+            if constexpr (VEC == 4) {
+                typedef float v4 __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(v4{o[0], o[1], o[2], o[3]}, reinterpret_cast<v4*>(d + (size_t)Y * W + Xu * 4));
+            } else {
+                d[(size_t)Y * W + Xu] = o[0];
+            }
+            Y += dY; Xu += dXu;
+            if (Xu >= Wu) { Xu -= Wu; ++Y; }
+        }
     }
 }
 
@@ -803,10 +831,15 @@ hipError_t launch_pblock_from_params(const SolveCtx& c, const float* d_cam, cons
     return hipGetLastError();
 }
 hipError_t launch_upsample(const float* src, int planes, int h, int w, int H, int W, float* dst, hipStream_t s) {
-    const size_t total = (size_t)planes * H * W;
-    if (total == 0) return hipSuccess;
-    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(upsample_bilinear_kernel, dim3(blocks), dim3(256), 0, s, src, planes, h, w, H, W, dst);
+    if ((size_t)planes * H * W == 0) return hipSuccess;
+    const bool vec4 = W % 4 == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;
+    const unsigned units = (unsigned)H * (unsigned)(vec4 ? W / 4 : W);
+    // ~4 units per thread and plane; planes on grid.y (strided beyond 65 535)
+    unsigned bx = (units + 256 * 4 - 1) / (256 * 4);
+    if (bx < 1) bx = 1;
+    const dim3 grid(bx, planes < 65535 ? planes : 65535), block(256);
+    if (vec4) hipLaunchKernelGGL(upsample_bilinear_kernel<4>, grid, block, 0, s, src, planes, h, w, H, W, dst);
+    else hipLaunchKernelGGL(upsample_bilinear_kernel<1>, grid, block, 0, s, src, planes, h, w, H, W, dst);
     return hipGetLastError();
 }
 
