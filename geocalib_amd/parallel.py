@@ -77,7 +77,8 @@ class CollectiveTimer:
 
 class GatherPlan:
     """Send / receive buffers of the result all-gather, allocated ONCE for a (n_total, world, device): nothing is
-    allocated inside a timed loop, and the padded send buffer is zeroed once."""
+    allocated inside a timed loop, and the padded send buffer is zeroed once.  With equal shards the gathered rows ARE
+    the receive buffer: results returned by a call that was given a plan alias it until the next call with that plan."""
 
     def __init__(self, n_total: int, world: int, device, dtype=torch.float32):
         self.n_total, self.world = n_total, world
