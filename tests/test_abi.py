@@ -99,3 +99,19 @@ def test_product_package_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")) or f == "Makefile":
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert not pat.search(txt), (dirpath, f, pat.search(txt).group(0))
+
+
+def test_documented_bindings_match_the_header():
+    """The ctypes stub shown in INTEGRATION.md and struct gclm_config of include/gclm.h list the same fields, in the
+    order of the binding the package itself uses (a stale stub would let gclm_default_config write past the struct)."""
+    import re
+    from conftest import ROOT
+    header = open(os.path.join(ROOT, "include", "gclm.h")).read()
+    body = header[header.index("typedef struct gclm_config {"):header.index("} gclm_config;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    in_header = [n for decl in re.findall(r"(?:int32_t|float)\s+([^;]+);", body) for n in re.split(r"\s*,\s*", decl.strip())]
+    ours = [n for n, _ in _lib.GclmConfig._fields_]
+    assert in_header == ours, (in_header, ours)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = doc[doc.index("class Config(C.Structure):"):doc.index("lib.gclm_last_error.restype")]
+    assert re.findall(r'\("(\w+)", C\.c_', stub) == ours
