@@ -552,9 +552,9 @@ def test_randomised_configurations_against_oracle(dev, oracle):
             # no reference golden for this (seed, case) (goldens exist for seeds 2024, 11, 12): whether the reference
             # reproduces itself on this draw is unknown (27 % do not), and the oracle's float32-vs-
             # float64 distance does not tell (fuzz 11/35: both oracles escape a stall the reference and the HIP path
-            # share; fuzz 14/97: the HIP path stalls at 1.8x the oracle's cost).  Without the reference's verdict nothing
-            # tight can be asserted: the result is finite (checked above) and the solve did not make the cost worse.
-            assert (out["final_cost"] <= 1.001 * out["initial_cost"] + 1e-6).all(), (case, (H, W), B, conf, out["final_cost"], out["initial_cost"])
+            # share; fuzz 14/97: the HIP path stalls at 1.8x the oracle's cost; and LM has no step rejection,
+            # lm_optimizer.py:606-613, so not even "the cost went down" holds).  Without the reference's verdict nothing
+            # beyond the finiteness checked above can be asserted on such a draw.
             undetermined += 1
             continue
         if own.max() > 1e-3:
