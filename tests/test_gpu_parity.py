@@ -170,6 +170,22 @@ def test_hip_matches_oracle_odd_shapes(dev, oracle, model, shape):
     compare_result(out, ref, tol, f"{model}/{shape}")
 
 
+@pytest.mark.parametrize("model", HIP_MODELS)
+@pytest.mark.parametrize("shape", [(24, 2600), (20, 2051), (40, 1280), (36, 516), (30, 36)])
+def test_hip_matches_oracle_tile_geometries(dev, oracle, model, shape):
+    """The column-stationary tiling of the sweep (plan_geometry): rows wider than 512 units are cut into strips (2600 px:
+    650 float4 units -> 3 strips; 2051 px, scalar path: 2051 units -> strips with idle lanes), 1280 px = 320 units is one
+    row per tile, 516 px = 129 units leaves idle lanes in every tile, 36 px packs 7 rows into a tile."""
+    from oracle import synth
+    H, W = shape
+    data, _, _ = synth.make_fields(7, range(2), model, H, W)
+    conf = {"camera_model": model, "num_steps": 20, "early_stop": False}
+    ref = oracle.solve(data, conf, precision="f32")
+    out = run(conf, data, dev)
+    compare_result(out, ref, TOL, f"{model}/{shape}")
+    assert np.array_equal(out["stop_at"], ref["stop_at"]) or H * W < 2000
+
+
 def test_hip_unaligned_views_take_scalar_path(dev, oracle):
     """Field tensors whose storage is not 16-byte aligned must still be handled (scalar loads)."""
     from geocalib_amd import LMOptimizer
