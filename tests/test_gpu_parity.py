@@ -171,19 +171,22 @@ def test_hip_matches_oracle_odd_shapes(dev, oracle, model, shape):
 
 
 @pytest.mark.parametrize("model", HIP_MODELS)
-@pytest.mark.parametrize("shape", [(24, 2600), (20, 2051), (40, 1280), (36, 516), (30, 36)])
+@pytest.mark.parametrize("shape", [(640, 2600), (500, 2051), (320, 1280), (200, 516), (30, 36)])
 def test_hip_matches_oracle_tile_geometries(dev, oracle, model, shape):
     """The column-stationary tiling of the sweep (plan_geometry): rows wider than 512 units are cut into strips (2600 px:
     650 float4 units -> 3 strips; 2051 px, scalar path: 2051 units -> strips with idle lanes), 1280 px = 320 units is one
-    row per tile, 516 px = 129 units leaves idle lanes in every tile, 36 px packs 7 rows into a tile."""
+    row per tile, 516 px = 129 units leaves idle lanes in every tile, 36 px packs 7 rows into a tile.  Cameras with a
+    narrow vertical field of view, so that the wide images stay well-posed (the horizontal field of view below ~100 deg)."""
     from oracle import synth
     H, W = shape
-    data, _, _ = synth.make_fields(7, range(2), model, H, W)
+    idx = [i for i in range(400) if synth.gt_params(7, i, model, H, W)[2][2] < np.deg2rad(28)][:2]
+    data, cams, _ = synth.make_fields(7, idx, model, H, W)
     conf = {"camera_model": model, "num_steps": 20, "early_stop": False}
     ref = oracle.solve(data, conf, precision="f32")
     out = run(conf, data, dev)
     compare_result(out, ref, TOL, f"{model}/{shape}")
-    assert np.array_equal(out["stop_at"], ref["stop_at"]) or H * W < 2000
+    assert np.abs(out["camera"][:, 3] / cams[:, 3] - 1).max() < 2e-2          # and it is the ground truth
+    assert np.abs(out["stop_at"] - ref["stop_at"]).max() <= 1
 
 
 def test_hip_unaligned_views_take_scalar_path(dev, oracle):
