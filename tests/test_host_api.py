@@ -223,3 +223,24 @@ def test_loop_rules_against_the_reference():
             c2, g2 = theirs.update_estimate(rc, rg, delta)
             assert torch.allclose(c1._data, c2._data, atol=1e-5, rtol=1e-6), (model, data)
             assert torch.allclose(g1._data, g2._data, atol=1e-6), (model, data)
+
+
+def test_training_mode_warns_that_no_gradient_flows(caplog):
+    """The HIP path is inference-only (an opaque C call under no_grad): in training mode, inputs that require gradients
+    get ONE warning (upstream's training-time optimiser backpropagates through the solve); the CPU tensors then hit the
+    no-CPU-fallback error as always."""
+    import logging
+    import pytest
+    from geocalib_amd import LMOptimizer
+    opt = LMOptimizer({"camera_model": "pinhole"}).train()
+    data = {"up_field": torch.zeros(1, 2, 8, 8, requires_grad=True), "latitude_field": torch.zeros(1, 1, 8, 8)}
+    with caplog.at_level(logging.WARNING, logger="geocalib_amd.lm_optimizer"):
+        for _ in range(2):
+            with pytest.raises(RuntimeError, match="no CPU fallback"):
+                opt(data)
+    assert sum("inference-only" in r.message for r in caplog.records) == 1
+    caplog.clear()
+    with caplog.at_level(logging.WARNING, logger="geocalib_amd.lm_optimizer"):
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            LMOptimizer({"camera_model": "pinhole"}).eval()(data)
+    assert not caplog.records                                   # eval mode: nothing to warn about
