@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--shared-group", type=int, default=0,
                     help="frames per shared-intrinsics group (BASELINE configs[4]: 16); 0 = independent intrinsics. "
                          "With N GPUs every group's frames are split over the ranks (one all-reduce per LM step)")
+    ap.add_argument("--shared-by-group", action="store_true",
+                    help="with --shared-group: every GPU owns WHOLE groups (no communication during the solve, one all-gather of "
+                         "results) instead of a slice of every group's frames")
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="images for the CPU baseline (-1: auto, 0: skip)")
     ap.add_argument("--no-timing", action="store_true", help="skip the in-library HIP-event timing of the sweeps")
@@ -160,6 +163,16 @@ def main():
 
         def step():
             return calibrate_sharded(opt, data, n_total, plan=plan, timer=ctimer)
+    elif args.shared_by_group:
+        # shared intrinsics sharded by group: rank r owns the groups of the frames [r*B, (r+1)*B); no collective in the solve
+        assert B % gs == 0, "the per-GPU batch must hold whole groups"
+        data, gt_cam, gt_grav = synth_fields(args.camera_model, B, H, W, dev, seed=args.seed, first_index=rank * B, group_size=gs)
+        opt = LMOptimizer({**conf, "shared_intrinsics": True, "group_size": gs}).eval()
+        ctimer = CollectiveTimer()
+        plan = GatherPlan(n_total, world, dev) if distributed else None
+
+        def step():
+            return calibrate_sharded(opt, data, n_total, plan=plan, timer=ctimer)
     else:
         # shared intrinsics: n_total/gs groups; every rank holds gs/world frames of EVERY group
         assert gs % world == 0 and B % (gs // world) == 0, "group size must be divisible by the number of GPUs"
@@ -247,15 +260,17 @@ def main():
                        "height": H, "width": W, "lm_steps": args.lm_steps, "planes": PLANES,
                        "parallelism": ("single GPU" if world == 1 else
                                        f"image-sharded x{world}, one all-gather of results" if gs == 0 else
+                                       f"group-sharded x{world}, one all-gather of results" if args.shared_by_group else
                                        f"frames of every group split x{world}, one all-reduce per LM step")},
             "check": {"median_focal_rel_err_vs_gt": f_err, "median_gravity_abs_err_vs_gt": g_err},
         }
         if distributed:
             result["multi_gpu"] = {
                 "ranks_seen": ranks_seen, "per_rank_ms": per_rank_ms,
-                "collective": "all_gather of packed result rows" if gs == 0 else "all_reduce(sum) of per-group Schur partials",
-                "collectives_per_step": 1 if gs == 0 else args.lm_steps,
-                "collective_bytes": (n_total * 4 * (8 + 3 + _lib.INFO_STRIDE) if gs == 0
+                "collective": ("all_gather of packed result rows" if gs == 0 or args.shared_by_group
+                               else "all_reduce(sum) of per-group Schur partials"),
+                "collectives_per_step": 1 if gs == 0 or args.shared_by_group else args.lm_steps,
+                "collective_bytes": (n_total * 4 * (8 + 3 + _lib.INFO_STRIDE) if gs == 0 or args.shared_by_group
                                      else (n_total // gs) * 4 * _lib.SHARED_PARTIAL_STRIDE),
                 "collective_ms": round(coll_ms_max, 4), "backend": args.backend}
         if sweep_n:

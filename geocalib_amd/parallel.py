@@ -5,6 +5,9 @@ contiguous image ranges, every rank solves its shard with ZERO communication, an
 result rows (camera 8 + gravity 3 + infos 48 floats = 236 B/image) are exchanged with ONE
 all-gather.  The payload is KBs: latency-bound, so everything is packed into a single collective.
 
+Shared intrinsics sharded by GROUP (every rank holds whole groups): the same -- no communication during the solve, one
+all-gather (`calibrate_sharded` with `group_size`); this is the partition to prefer whenever it is possible.
+
 Shared intrinsics with a group's frames split across ranks (BASELINE config 5): per LM step every
 rank reduces its frames to per-group Schur partials (32 floats/group, csrc/gclm_update.hip), ONE
 all-reduce(sum) over all groups, then every rank solves the tiny Schur systems redundantly and
@@ -187,12 +190,20 @@ def infos_from_rows(opt: LMOptimizer, rows: torch.Tensor, has_up: bool) -> Dict[
 def calibrate_sharded(opt: LMOptimizer, local_data: Dict[str, torch.Tensor], n_total: int,
                       group=None, comm: "RcclComm" = None, plan: GatherPlan = None,
                       timer: CollectiveTimer = None) -> Dict[str, torch.Tensor]:
-    """Solve this rank's shard (independent intrinsics) and all-gather everybody's results.
+    """Solve this rank's shard (independent intrinsics, or whole shared-intrinsics groups) and all-gather everybody's
+    results.
 
     `local_data` holds the fields of the images [shard_range(n_total, rank, world)) of the global
     batch; the returned dict covers all `n_total` images on every rank.  `plan` (GatherPlan) keeps the exchange
     buffers across calls, `timer` (CollectiveTimer) accumulates the device time of the collective."""
-    assert not opt.shared_intrinsics, "use SharedIntrinsicsSplit for shared intrinsics"
+    if opt.shared_intrinsics:
+        # shared intrinsics shard by GROUP: every rank holds whole groups (frames of a group contiguous), solves them with
+        # no communication and joins the single all-gather.  Frames of ONE group spread over ranks: SharedIntrinsicsSplit.
+        gs = opt.conf.group_size
+        n_local = next(iter(local_data.values())).shape[0]
+        assert gs and n_local % gs == 0 and n_total % gs == 0, (
+            "calibrate_sharded with shared intrinsics needs `group_size` and whole groups per rank; "
+            "use SharedIntrinsicsSplit when the frames of a group live on several ranks")
     if opt.conf.early_stop and (comm is not None and comm.nranks > 1 or collectives_on(group)):
         # the reference's early stop is ONE decision over the whole batch (lm_optimizer.py:90-92, 619); each rank
         # would take it over its own shard and the gathered result would depend on the world size (SURVEY 8-B quirk 3)

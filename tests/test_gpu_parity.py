@@ -668,7 +668,7 @@ def test_c_abi_from_plain_c(dev, tmp_path):
         assert np.allclose(got[:, 3:6], out["gravity"], atol=2e-5)
 
 
-@pytest.mark.parametrize("extra", [[], ["--shared-group", "16"]])
+@pytest.mark.parametrize("extra", [[], ["--shared-group", "16"], ["--shared-group", "16", "--shared-by-group"]])
 def test_bench_multi_rank_path_on_one_gpu(dev, extra):
     """bench.py's N>1 code path (image sharding + ONE gather; shared-intrinsics frame split + ONE all-reduce per
     step) with two real processes that share this GPU and talk over gloo: the JSON line must describe the
@@ -692,7 +692,7 @@ def test_bench_multi_rank_path_on_one_gpu(dev, extra):
     # the N>1 line is attributable: ranks seen by the communicator, every rank's own step time, time in the collective
     mg = out["multi_gpu"]
     assert mg["ranks_seen"] == 2 and len(mg["per_rank_ms"]) == 2 and all(t > 0 for t in mg["per_rank_ms"])
-    assert mg["collective_ms"] >= 0 and mg["collectives_per_step"] == (20 if extra else 1)
+    assert mg["collective_ms"] >= 0 and mg["collectives_per_step"] == (20 if extra == ["--shared-group", "16"] else 1)
     assert len(out["ms_per_step_repeats"]) == out["repeats"] == 3
 
 
