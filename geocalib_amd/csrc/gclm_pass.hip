@@ -62,6 +62,12 @@
 #ifndef GCLM_DIV_LITERAL
 #define GCLM_DIV_LITERAL 0
 #endif
+#ifndef GCLM_RADIAL_WAVES
+#define GCLM_RADIAL_WAVES 3
+#endif
+#ifndef GCLM_RADIAL_DOT
+#define GCLM_RADIAL_DOT 1           // A/B switch: 0 = radial keeps the explicit-ray latitude block
+#endif
 #ifndef GCLM_NT_LOADS
 #define GCLM_NT_LOADS 1
 #endif
@@ -519,9 +525,16 @@ __device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& 
                     if constexpr (MODEL == GCLM_RADIAL) s[2] = vfma(R.s2x4 * t, uvw * nuv, s[2]);
                 }
             }
+            if constexpr (MODEL == GCLM_RADIAL) {
+                // dq/dk1 = r2 p + 2 t uv,  dq/dk2 = r4 p + 4 r2 t uv = r2 (dq/dk1 + 2 t uv)                 (:170-180)
+                const F tn2 = (t * 2.0f) * nuv;
+                s[3] = vfma(r2, np_, tn2);
+                s[4] = r2 * (s[3] + tn2);
+            } else {
 #pragma unroll
-            for (int j = 0; j < ND; ++j)                 // dq/dk_j = (ds/dk_j) p + 2 (ds1/dk_j) t (u,v)   (:170-180)
-                s[3 + j] = vfma(R.ds[j], np_, (R.ds1x2[j] * t) * nuv);
+                for (int j = 0; j < ND; ++j)             // dq/dk_j = (ds/dk_j) p + 2 (ds1/dk_j) t (u,v)   (:170-180)
+                    s[3 + j] = vfma(R.ds[j], np_, (R.ds1x2[j] * t) * nuv);
+            }
         }
         const F rho = vfma(ux, ry, -(uy * rx));
         if constexpr (EMIT == 1) {
@@ -542,9 +555,10 @@ __device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& 
         }
     }
 
-    // The dot-product form of the latitude block is 2-3 % faster for simple_divisional (and the two fast-path
-    // models) but pushes radial (24 accumulator pairs) past 168 VGPRs into spills: -3 % there, so it keeps rays.
-    if constexpr (MODEL != GCLM_RADIAL) {
+    // The dot-product form of the latitude block is 2-3 % faster for simple_divisional and the two fast-path models.
+    // radial (24 accumulator pairs, held to 168 VGPRs = 3 waves per SIMD) spills 12 bytes with it and is still 1.5 %
+    // faster than with the explicit ray (1200 vs 1220 us at B = 1024; at 2 waves per SIMD and no spill: 1265 us).
+    if constexpr (MODEL != GCLM_RADIAL || GCLM_RADIAL_DOT) {
         {   // latitude (ray = (tau u, tau v, 1)/n only through dot products, see pixel_accumulate_fast)
             const F tr2 = DIST ? R.tau * r2 : r2;
             const F nn = DIST ? vfma(R.tau, tr2, vsplat(u, 1.0f)) : r2 + 1.0f;
@@ -721,7 +735,7 @@ struct Lane<1> {
 template <int MODEL, bool HAS_UP, bool HAS_UPC, bool HAS_LATC, bool LOGF, int VEC>
 // launch bounds: radial / simple_divisional are held to 168 VGPRs (3 waves per SIMD); the two BASELINE models
 // reach 96 / 128 on their own
-__global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL >= GCLM_RADIAL) ? 3 : (VEC == 4 && MODEL == GCLM_SIMPLE_RADIAL) ? 4 : GCLM_MIN_WAVES) void sweep_kernel(
+__global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL == GCLM_RADIAL) ? GCLM_RADIAL_WAVES : (VEC == 4 && MODEL > GCLM_RADIAL) ? 3 : (VEC == 4 && MODEL == GCLM_SIMPLE_RADIAL) ? 4 : GCLM_MIN_WAVES) void sweep_kernel(
     const SweepArgs a) {
     if (stop_fired_before(a.ctrl, a.stop_step)) return;   // batch-global early stop, no host sync
     constexpr int NACC = Layout<MODEL>::NACC;
