@@ -29,17 +29,18 @@
 //   tau = 1-k1 r2+(3k1^2-k2) r4.  simple_divisional: s = (1-sqrt(1-4k r2))/(2k r2), tau = 1/(1+k r2)
 //   with the reference's own guards (camera.py:829-940).
 //
-// Mapping to the machine: grid = (chunks per image, B); a 256-thread workgroup (4 waves of 64)
-// streams a contiguous run of float4 groups of one image with fully coalesced, non-temporal
-// 16 B/lane loads (1 KiB per wave-instruction per plane); the 80-byte parameter block of the image
-// is read with scalar loads (workgroup-uniform -> SGPRs); 16 (24 for `radial`) accumulators per lane
-// are reduced per wave with DPP adds (no LDS), then across the 4 waves through LDS, and ONE partial record per
-// workgroup is written (no atomics: bit-reproducible).  No MFMA: the contraction is N x P -> P x P,
-// P <= 5.
+// Mapping to the machine: grid = (workgroups per image, B), 256-thread workgroups (4 waves of 64).  Every wave is a
+// "job": 64 consecutive lanes of a column-stationary tile (rpi rows x one row-wide strip of float4 groups) that walks down
+// the image, so a lane never changes its column: the column terms leave the loop, a wave-instruction still reads 1 KiB of
+// consecutive addresses per plane (fully coalesced, non-temporal 16 B/lane loads, uniform base + one 32-bit offset for
+// all planes) -- see sweep_kernel.  The 80-byte parameter block of the image is read with scalar loads
+// (workgroup-uniform -> SGPRs); 16 (24 for `radial`) accumulators per lane are reduced per wave with DPP adds (no LDS),
+// then across the 4 waves through LDS, and ONE partial record per workgroup is written (no atomics:
+// bit-reproducible).  No MFMA: the contraction is N x P -> P x P, P <= 5.
 //
-// Arithmetic: PMC counters (profiles/r01_pmc_sq_*) show the sweep is fp32-VALU-bound as soon as
-// it approaches ~6 TB/s (scripts/valu_probe.hip: a packed op costs ~1.8x a scalar one, i.e. the bound is
-// FLOPs at 32 lanes/SIMD/cycle), so every flop taken out of the pixel body counts; the float4 path computes PIXEL PAIRS in packed fp32 (v_pk_fma_f32 /
+// Arithmetic: the distortion models are VALU-heavy enough to pull the chip's clock down (power), so every
+// flop taken out of the pixel body counts (scripts/valu_probe.hip: a packed op costs ~1.8x a scalar one, i.e. the unit
+// is FLOPs at 32 lanes/SIMD/cycle); the float4 path computes PIXEL PAIRS in packed fp32 (v_pk_fma_f32 /
 // v_pk_mul_f32 / v_pk_add_f32: two pixels per instruction) -- written explicitly on a 2-wide vector
 // type so the pairs live in adjacent registers straight out of the dwordx4 loads (LLVM's SLP
 // vectoriser finds some of these pairs on its own but pays for them with register shuffles and 2x
