@@ -38,13 +38,19 @@ int main(int argc, char** argv) {
         fprintf(stderr, "gclm_synth_fields failed\n");
         return 3;
     }
+    if (gclm_version() != GCLM_VERSION || gclm_abi_config_size() != (int)sizeof(gclm_config)) {
+        fprintf(stderr, "libgeocalib_hip.so is ABI %d (config %d bytes), this program was built for %d (%d bytes)\n",
+                gclm_version(), gclm_abi_config_size(), GCLM_VERSION, (int)sizeof(gclm_config));
+        return 4;
+    }
     gclm_config cfg;
     gclm_default_config(&cfg);
+    cfg.device = 0;
     cfg.camera_model = model;
     cfg.num_steps = 20;
     cfg.early_stop = 0;
     gclm_handle* h = NULL;
-    if (gclm_create(&h, &cfg, 0) != 0) {
+    if (gclm_create(&h, &cfg) != 0) {
         fprintf(stderr, "gclm_create: %s\n", gclm_last_error(NULL));
         return 4;
     }

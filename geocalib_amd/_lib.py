@@ -16,6 +16,7 @@ INFO_STRIDE = 48
 SHARED_PARTIAL_STRIDE = 32
 COMM_ID_BYTES = 128
 MAX_PARAMS = 5
+ABI_VERSION = 300          # GCLM_VERSION of include/gclm.h this binding was written against
 INFO = {"stop_at": 0, "initial_up_cost": 1, "initial_latitude_cost": 2, "initial_cost": 3,
         "final_up_cost": 4, "final_latitude_cost": 5, "final_cost": 6, "roll_uncertainty": 7,
         "pitch_uncertainty": 8, "gravity_uncertainty": 9, "focal_uncertainty": 10,
@@ -25,7 +26,8 @@ INFO = {"stop_at": 0, "initial_up_cost": 1, "initial_latitude_cost": 2, "initial
 class GclmConfig(C.Structure):
     """struct gclm_config (include/gclm.h)."""
 
-    _fields_ = [("camera_model", C.c_int32), ("shared_intrinsics", C.c_int32),
+    _fields_ = [("struct_size", C.c_int32), ("abi_version", C.c_int32), ("device", C.c_int32),
+                ("camera_model", C.c_int32), ("shared_intrinsics", C.c_int32),
                 ("group_size", C.c_int32), ("num_steps", C.c_int32), ("lambda0", C.c_float),
                 ("fix_lambda", C.c_int32), ("early_stop", C.c_int32), ("atol", C.c_float),
                 ("rtol", C.c_float), ("use_spherical_manifold", C.c_int32),
@@ -36,6 +38,15 @@ class GclmConfig(C.Structure):
 
     def key(self):
         return tuple(getattr(self, f) for f, _ in self._fields_)
+
+    @classmethod
+    def default(cls, device: int = 0) -> "GclmConfig":
+        """gclm_default_config: LMOptimizer.default_conf plus the library's struct_size / abi_version stamp."""
+        cfg = cls()
+        if load().gclm_default_config(C.byref(cfg)) != 0:
+            raise GclmError("gclm_default_config failed")
+        cfg.device = int(device)
+        return cfg
 
 
 class GclmError(RuntimeError):
@@ -48,7 +59,8 @@ _P = C.c_void_p
 _SIGNATURES = {
     "gclm_version": (C.c_int, []),
     "gclm_default_config": (C.c_int, [C.POINTER(GclmConfig)]),
-    "gclm_create": (C.c_int, [C.POINTER(_P), C.POINTER(GclmConfig), C.c_int]),
+    "gclm_abi_config_size": (C.c_int, []),
+    "gclm_create": (C.c_int, [C.POINTER(_P), C.POINTER(GclmConfig)]),
     "gclm_configure": (C.c_int, [_P, C.POINTER(GclmConfig)]),
     "gclm_destroy": (C.c_int, [_P]),
     "gclm_last_error": (C.c_char_p, [_P]),
@@ -77,6 +89,7 @@ _SIGNATURES = {
     "gclm_comm_last_error": (C.c_char_p, [_P]),
     "gclm_comm_all_gather": (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
     "gclm_comm_all_reduce_sum": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "gclm_set_sweep_iters": (C.c_int, [_P, C.c_int]),
     "gclm_set_timing": (C.c_int, [_P, C.c_int]),
     "gclm_last_pass_timing": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
 }
@@ -95,6 +108,10 @@ def load():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
+        # a library of another ABI generation must not be driven with this binding's struct layout
+        if lib.gclm_version() != ABI_VERSION or lib.gclm_abi_config_size() != C.sizeof(GclmConfig):
+            raise ImportError(f"{LIB_PATH}: ABI {lib.gclm_version()} / sizeof(gclm_config) {lib.gclm_abi_config_size()}, "
+                              f"this binding expects {ABI_VERSION} / {C.sizeof(GclmConfig)}: rebuild the library")
         _lib = lib
     return _lib
 

@@ -15,6 +15,10 @@
 
 using namespace gclm;
 
+#ifndef GCLM_ISO_FINAL
+#define GCLM_ISO_FINAL 1      // A/B switch: 0 = the final sweep always takes the general focal column
+#endif
+
 struct gclm_handle {
     gclm_config cfg;
     int device = 0;
@@ -32,6 +36,7 @@ struct gclm_handle {
         float *cam_io = nullptr, *grav_io = nullptr;
         Geometry geo{};
     } sh;
+    int sweep_iters = 0;            // gclm_set_sweep_iters: 0 = built-in choice
     // optional timing of the sweep launches
     bool timing = false;
     std::vector<hipEvent_t> ev;
@@ -57,6 +62,15 @@ int fail(gclm_handle* h, int code, const char* fmt, ...) {
         hipError_t e_ = (expr);                                                             \
         if (e_ != hipSuccess) return fail(h, -10, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
+
+// A caller built against another include/gclm.h must be told so, not trusted with a struct of another layout.
+const char* abi_mismatch(const gclm_config* c, char (&buf)[256]) {
+    if (c->struct_size == (int32_t)sizeof(gclm_config) && c->abi_version == GCLM_VERSION) return nullptr;
+    snprintf(buf, sizeof(buf), "gclm_config ABI mismatch: caller passes struct_size %d / abi_version %d, this library is "
+             "sizeof(gclm_config) %d / GCLM_VERSION %d (rebuild the caller against this include/gclm.h and fill the "
+             "struct with gclm_default_config)", (int)c->struct_size, (int)c->abi_version, (int)sizeof(gclm_config), GCLM_VERSION);
+    return buf;
+}
 
 const char* validate(const gclm_config& c) {
     if (c.camera_model < GCLM_PINHOLE || c.camera_model > GCLM_SIMPLE_DIVISIONAL)
@@ -134,7 +148,9 @@ SweepArgs sweep_args(const gclm_handle* h, const float* up, const float* lat, co
     a.B = h->ctx.B; a.H = h->ctx.H; a.W = h->ctx.W;
     a.nchunks = g.nchunks; a.vec = g.vec;
     a.wu = g.wu; a.cu = g.cu; a.nstrips = g.nstrips; a.rpi = g.rpi; a.rows_per_block = g.rows_per_block; a.wpt = g.wpt; a.jobs = g.jobs;
-    a.log_focal = loop_params && h->cfg.use_log_focal;   // else the (roll, pitch, focal) block of the final sweep
+    // loop sweeps: the configured parametrisation; final sweep: the (roll, pitch, focal) block, in its log-focal form when
+    // every image is known to have fx == fy (iso_final: finalize_kernel rescales the focal column)
+    a.log_focal = loop_params ? h->cfg.use_log_focal : h->ctx.iso_final;
     a.stop_step = stop_step;
     a.up_scale = h->cfg.up_loss_fn_scale; a.lat_scale = h->cfg.lat_loss_fn_scale;
     return a;
@@ -187,7 +203,7 @@ namespace gclm {
 // then for the smallest tile (640 px: 160 units, rpi = 2, 320 lanes = 5 waves, no idle lane).  Wider rows are cut
 // into strips of a multiple of 64 units, one row per iteration.  Every wave of a tile is a job; a workgroup is four
 // consecutive jobs of an image.
-Geometry plan_geometry(int B, int H, int W, bool aligned16) {
+Geometry plan_geometry(int B, int H, int W, bool aligned16, int sweep_iters) {
     Geometry g;
     g.vec = (aligned16 && (W % 4 == 0)) ? 4 : 1;
     g.wu = W / g.vec;
@@ -217,11 +233,7 @@ Geometry plan_geometry(int B, int H, int W, bool aligned16) {
     }
     // ~20 loop iterations per lane amortise the 16-value workgroup reduction; fewer when the batch alone cannot
     // fill 256 CUs x 4+ workgroups.
-    int iters = 20;
-    if (const char* e = std::getenv("GCLM_SWEEP_ITERS")) {      // tuning experiments only (scripts/README.md)
-        const int v = std::atoi(e);
-        if (v >= 1 && v <= 4096) iters = v;
-    }
+    int iters = (sweep_iters >= 1 && sweep_iters <= 4096) ? sweep_iters : 20;   // gclm_set_sweep_iters (tuning / tests)
     auto jobs = [&](int it) { return g.nstrips * g.wpt * ((H + g.rpi * it - 1) / (g.rpi * it)); };
     auto chunks = [&](int it) { return (jobs(it) + kBlock / 64 - 1) / (kBlock / 64); };
     while (iters > 2 && (long long)B * chunks(iters) < 2048) iters = iters > 5 ? iters / 2 : iters - 1;
@@ -236,9 +248,14 @@ extern "C" {
 
 int gclm_version(void) { return GCLM_VERSION; }
 
+int gclm_abi_config_size(void) { return (int)sizeof(gclm_config); }
+
 int gclm_default_config(gclm_config* cfg) {
     if (!cfg) return -1;
     std::memset(cfg, 0, sizeof(*cfg));
+    cfg->struct_size = (int32_t)sizeof(gclm_config);
+    cfg->abi_version = GCLM_VERSION;
+    cfg->device = 0;
     cfg->camera_model = GCLM_PINHOLE;
     cfg->num_steps = 30;
     cfg->lambda0 = 0.1f;
@@ -254,10 +271,13 @@ int gclm_default_config(gclm_config* cfg) {
     return 0;
 }
 
-int gclm_create(gclm_handle** out, const gclm_config* cfg, int device) {
+int gclm_create(gclm_handle** out, const gclm_config* cfg) {
     if (!out || !cfg) return fail(nullptr, -1, "gclm_create: null argument");
     *out = nullptr;
+    char abuf[256];
+    if (const char* msg = abi_mismatch(cfg, abuf)) return fail(nullptr, -5, "gclm_create: %s", msg);
     if (const char* msg = validate(*cfg)) return fail(nullptr, -2, "gclm_create: %s", msg);
+    const int device = cfg->device;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, -11, "gclm_create: no HIP device visible (the HIP path has no CPU fallback)");
@@ -272,7 +292,10 @@ int gclm_create(gclm_handle** out, const gclm_config* cfg, int device) {
 
 int gclm_configure(gclm_handle* h, const gclm_config* cfg) {
     if (!h || !cfg) return -1;
+    char abuf[256];
+    if (const char* msg = abi_mismatch(cfg, abuf)) return fail(h, -5, "gclm_configure: %s", msg);
     if (const char* msg = validate(*cfg)) return fail(h, -2, "gclm_configure: %s", msg);
+    if (cfg->device != h->device) return fail(h, -2, "gclm_configure: a handle cannot move from device %d to %d", h->device, (int)cfg->device);
     h->cfg = *cfg;
     h->sh.active = false;
     return 0;
@@ -290,6 +313,14 @@ int gclm_destroy(gclm_handle* h) {
 const char* gclm_last_error(const gclm_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 size_t gclm_workspace_bytes(const gclm_handle* h) { return h ? h->ws_bytes : 0; }
+
+int gclm_set_sweep_iters(gclm_handle* h, int iters) {
+    if (!h) return -1;
+    if (iters < 0 || iters > 4096) return fail(h, -3, "gclm_set_sweep_iters: %d out of range [0, 4096]", iters);
+    h->sweep_iters = iters;
+    h->sh.active = false;
+    return 0;
+}
 
 int gclm_set_timing(gclm_handle* h, int enabled) {
     if (!h) return -1;
@@ -324,10 +355,13 @@ static int run_solve(gclm_handle* h, const float* d_up, const float* d_lat, cons
     DeviceGuard guard(h->device);
     GCLM_HIP(h, guard.status);
     const bool al = is_aligned16(d_up) && is_aligned16(d_lat) && is_aligned16(d_up_conf) && is_aligned16(d_lat_conf);
-    const Geometry geo = plan_geometry(B, H, W, al);
+    const Geometry geo = plan_geometry(B, H, W, al, h->sweep_iters);
     SolveCtx& c = h->ctx;
     c.cfg = h->cfg;
     c.B = B; c.H = H; c.W = W; c.nchunks = geo.nchunks;
+    // trivial / heuristic initial estimate without `scales`: fx == fy at the start, and update_focal keeps the ratio
+    // (camera.py:148) -- the final sweep may then run the cheaper log-focal instantiation (see finalize_kernel)
+    c.iso_final = (ia.cam == nullptr && ia.scales == nullptr && GCLM_ISO_FINAL) ? 1 : 0;
     if (int rc = setup_groups(h, B)) return rc;
     if (int rc = ensure_workspace(h, B, geo.nchunks, c.n_groups)) return rc;
     h->sh.active = false;
@@ -393,11 +427,11 @@ int gclm_system(gclm_handle* h, const float* d_up, const float* d_lat, const flo
     DeviceGuard guard(h->device);
     GCLM_HIP(h, guard.status);
     const bool al = is_aligned16(d_up) && is_aligned16(d_lat) && is_aligned16(d_up_conf) && is_aligned16(d_lat_conf);
-    const Geometry geo = plan_geometry(B, H, W, al);
+    const Geometry geo = plan_geometry(B, H, W, al, h->sweep_iters);
     SolveCtx& c = h->ctx;
     c.cfg = h->cfg;
     c.B = B; c.H = H; c.W = W; c.nchunks = geo.nchunks;
-    c.n_groups = 0; c.group_size = 1; c.group_of_frame = nullptr;
+    c.n_groups = 0; c.group_size = 1; c.group_of_frame = nullptr; c.iso_final = 0;
     if (int rc = ensure_workspace(h, B, geo.nchunks, 0)) return rc;
     h->sh.active = false;
     GCLM_HIP(h, launch_pblock_from_params(c, d_cam, d_grav, as_rpf, c.pb_final, s));
@@ -420,11 +454,11 @@ int gclm_shared_begin(gclm_handle* h, const float* d_up, const float* d_lat, con
     GCLM_HIP(h, guard.status);
     const bool al = is_aligned16(d_up) && is_aligned16(d_lat) && is_aligned16(d_up_conf) && is_aligned16(d_lat_conf);
     const int Bp = B_local > 0 ? B_local : 1;
-    h->sh.geo = plan_geometry(Bp, H, W, al);
+    h->sh.geo = plan_geometry(Bp, H, W, al, h->sweep_iters);
     SolveCtx& c = h->ctx;
     c.cfg = h->cfg;
     c.B = B_local; c.H = H; c.W = W; c.nchunks = h->sh.geo.nchunks;
-    c.n_groups = num_groups; c.group_size = 1; c.group_of_frame = d_group_of_frame;
+    c.n_groups = num_groups; c.group_size = 1; c.group_of_frame = d_group_of_frame; c.iso_final = 0;
     if (int rc = ensure_workspace(h, Bp, h->sh.geo.nchunks, num_groups)) return rc;
     h->sh.up = d_up; h->sh.lat = d_lat; h->sh.upc = d_up_conf; h->sh.latc = d_lat_conf;
     h->sh.cam_io = d_cam_io; h->sh.grav_io = d_grav_io;

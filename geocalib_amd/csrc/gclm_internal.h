@@ -90,7 +90,7 @@ struct Geometry {          // how a sweep is cut into blocks (column-stationary 
     int vec, nchunks;
     int wu, cu, nstrips, rpi, rows_per_block, wpt, jobs;
 };
-Geometry plan_geometry(int B, int H, int W, bool aligned16);
+Geometry plan_geometry(int B, int H, int W, bool aligned16, int sweep_iters = 0);
 
 // gclm_pass.hip
 hipError_t launch_gradient_hessian(const float* d_J, const float* d_r, const float* d_w, int B, int N, int R, int P,
@@ -109,6 +109,8 @@ hipError_t launch_sweep(int camera_model, const SweepArgs& a, hipStream_t s);
 struct SolveCtx {
     gclm_config cfg;
     int B, H, W, nchunks;
+    int iso_final;              // the final (uncertainty) sweep runs in the log-focal form and finalize rescales its focal
+                                //   column by 1/f: valid when fx == fy for every image (gclm_calibrate without `scales`)
     int n_groups, group_size;   // shared intrinsics
     const int32_t* group_of_frame; // device (B), non-decreasing group id per frame, or nullptr (uniform group_size)
     State* state[2];

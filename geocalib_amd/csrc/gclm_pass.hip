@@ -51,6 +51,9 @@
 #ifndef GCLM_MIN_WAVES
 #define GCLM_MIN_WAVES 1
 #endif
+#ifndef GCLM_PINHOLE_WAVES
+#define GCLM_PINHOLE_WAVES 6
+#endif
 #ifndef GCLM_LOGF
 #define GCLM_LOGF 1            // A/B switch: 0 = always the general focal-column code
 #endif
@@ -71,6 +74,9 @@
 #endif
 #ifndef GCLM_NT_LOADS
 #define GCLM_NT_LOADS 1
+#endif
+#ifndef GCLM_DIV_GUARD_ALWAYS
+#define GCLM_DIV_GUARD_ALWAYS 0     // A/B switch: 1 = simple_divisional always runs the guarded body (round-2 behaviour)
 #endif
 
 namespace gclm {
@@ -121,16 +127,31 @@ __device__ __forceinline__ float hsum(float a) { return a; }
 __device__ __forceinline__ float hsum(f2 a) { return a.x + a.y; }
 
 // sin(x) for |x| <= pi/2 (odd minimax polynomial, |err| < 1.2e-7 in fp32).  Latitudes are
-// asin(clamp(tanh)) outputs of the CNN head (geocalib.py:73-75) and therefore in range.
+// asin(clamp(tanh)) outputs of the CNN head (geocalib.py:73-75) and therefore in range; the reference takes
+// torch.sin of whatever the caller passes (lm_optimizer.py:262,270), so anything outside is FOLDED into the
+// range first (fold_halfpi) -- behind a wave-uniform branch in the sweep that in-range data never takes.
+constexpr float kHalfPi = 1.57079632679489661923f;
+// x -> r in [-pi/2, pi/2] with sin(r) = sin(x):  k = rint(x / pi), r = (-1)^k (x - k pi)  (two-term Cody-Waite, exact
+// enough for |k| < 1e4: degrees fed as radians give k <= 29).  In-range x (k = 0) comes back bit-identical.
+__device__ __forceinline__ float fold_halfpi(float x) {
+    const float k = rintf(x * 0.318309886183790671538f);
+    float r = fmaf(k, -3.14159274101257324219f, x);            // pi rounded to float ...
+    r = fmaf(k, 8.74227765734758577e-08f, r);                 // ... and what the rounding dropped
+    return (((int)k) & 1) ? -r : r;
+}
+__device__ __forceinline__ bool beyond_halfpi(float a) { return fabsf(a) > kHalfPi; }
+// the sweep tests t = x^2 (which the polynomial needs anyway) against a threshold a hair beyond (pi/2)^2
+constexpr float kHalfPiSq = 2.4675f;
 template <typename F>
-__device__ __forceinline__ F sin_halfpi(F x) {
-    const F t = x * x;
+__device__ __forceinline__ F sin_halfpi(F x, F t) {          // t = x * x
     F p = vsplat(x, 2.6000457182817627e-06f);
     p = vfma(p, t, vsplat(x, -0.00019806611817330122f));
     p = vfma(p, t, vsplat(x, 0.008333017118275166f));
     p = vfma(p, t, vsplat(x, -0.16666656732559204f));
     return vfma(x * t, p, x);
 }
+template <typename F>
+__device__ __forceinline__ F sin_halfpi(F x) { return sin_halfpi(x, x * x); }
 
 // Scaled Huber on the squared residual x2 (lm_optimizer.py:61-87), in units of a^2 (the a^2 factor of the cost
 // is applied once per workgroup): adds confidence * cost / a^2 to `cost_acc` and returns confidence * weight.
@@ -169,7 +190,11 @@ struct Radial {
     F tau, tau1x2, dtau[2];       // undistortion scale, 2 tau1, dtau/dk_j
 };
 
-template <int MODEL, typename F>
+// GUARD (simple_divisional only): the reference's masked_fill(x == 0, 1e6) on the denominators that carry a factor r2
+// or r2 k.  They can only fire at the principal point (r2 == 0: at most one pixel of an image) or while k == 0 (the
+// first sweep), so the sweep picks, per wave and iteration, a copy of the body without those selects whenever no lane
+// can need them (GUARD = false: same operations on the same values, hence the same bits; see sweep_kernel).
+template <int MODEL, typename F, bool GUARD = true>
 __device__ __forceinline__ void radial_terms(const PBlock& P, F r2, Radial<F>& R) {
     const F one = vsplat(r2, 1.0f), zero = vsplat(r2, 0.f);
     R.s = R.tau = one;
@@ -250,28 +275,30 @@ __device__ __forceinline__ void radial_terms(const PBlock& P, F r2, Radial<F>& R
         const F ir2 = vrcp_hw(r2), ir4 = ir2 * ir2, ir6 = ir4 * ir2;    // inf for r2 = 0: only read behind the selects
         const F omt = one - t1;
         const F r4 = r2 * r2;
-        R.s = vsel_eq0(rk, one, (one - ssq) * (ir2 * (0.5f * ik)));   // den = 2 k r2
+        // guarded reciprocal: select(indicator == 0, a, b); without GUARD the caller has made sure indicator != 0
+        auto sel0 = [](F d, F a, F b) { if constexpr (GUARD) return vsel_eq0(d, a, b); else return b; };
+        R.s = sel0(rk, one, (one - ssq) * (ir2 * (0.5f * ik)));   // den = 2 k r2
         {   // J_distort scale2pts (:843-851): off = uv (4 d2 - (1-t1) d1)/(d1 d2), d1 = 2 t1 r2, d2 = k r4
             const F d1 = t1 * (2.0f * r2), d2 = r4 * k;
-            R.s1x2 = vfma(d2, vsplat(r2, 4.0f), -(omt * d1)) * vsel_eq0(rk, tiny, (ir6 * it1) * (0.5f * ik));
+            R.s1x2 = vfma(d2, vsplat(r2, 4.0f), -(omt * d1)) * sel0(rk, tiny, (ir6 * it1) * (0.5f * ik));
         }
         {   // J_up_projection_offset wrt uv (:912-940): diagonal jd and the uv uv^T coefficient
             const F i_r2t1 = ir2 * it1, i_r4t1 = ir4 * it1;
-            R.jd = 4.0f * vsel_eq0(r2, tiny, 0.5f * i_r2t1) - omt * vsel_eq0(rk, tiny, ir4 * ik);
-            F pc = -16.0f * vsel_eq0(r2, tiny, 0.25f * i_r4t1);
-            pc = pc + (32.0f * k) * vsel_eq0(r2, tiny, 0.25f * (i_r2t1 * it0));
-            pc = pc - 4.0f * vsel_eq0(r2, tiny, i_r4t1);
-            pc = pc + 4.0f * omt * vsel_eq0(rk, tiny, ir6 * ik);
+            R.jd = 4.0f * sel0(r2, tiny, 0.5f * i_r2t1) - omt * sel0(rk, tiny, ir4 * ik);
+            F pc = -16.0f * sel0(r2, tiny, 0.25f * i_r4t1);
+            pc = pc + (32.0f * k) * sel0(r2, tiny, 0.25f * (i_r2t1 * it0));
+            pc = pc - 4.0f * sel0(r2, tiny, i_r4t1);
+            pc = pc + 4.0f * omt * sel0(rk, tiny, ir6 * ik);
             R.s2x4 = pc;
         }
         {   // J_distort scale2dist (:853-857): (2 d2 - (1-t1) d1)/(d1 d2), d1 = 2 k t1, d2 = 2 r2 k^2
             const F d1 = t1 * (2.0f * k), d2 = r2 * (2.0f * k * k);
-            R.ds[0] = vfma(d2, vsplat(r2, 2.0f), -(omt * d1)) * vsel_eq0(rk, tiny, (ir2 * it1) * (0.25f * ik * ik * ik));
+            R.ds[0] = vfma(d2, vsplat(r2, 2.0f), -(omt * d1)) * sel0(rk, tiny, (ir2 * it1) * (0.25f * ik * ik * ik));
         }
         {   // J_up_projection_offset wrt dist (:898-911); 4 t0 t1 > 0 needs no guard
             F J = 4.0f * (it0 * it1);
-            J = J - 2.0f * vsel_eq0(rk, tiny, (ir2 * it1) * ik);
-            J = J + omt * vsel_eq0(rk, tiny, ir4 * (ik * ik));
+            J = J - 2.0f * sel0(rk, tiny, (ir2 * it1) * ik);
+            J = J + omt * sel0(rk, tiny, ir4 * (ik * ik));
             R.ds1x2[0] = J;
         }
         const F den2 = vfma(r2, vsplat(r2, k), one);                  // 1 + k r2
@@ -313,7 +340,7 @@ __device__ __forceinline__ void accumulate(F (&acc)[Layout<MODEL>::NACC], const 
 //   up:  s2 = c (m.uv) - 2 k1 s3          lat:  l2 = -e (h.uv) - 2 k1 l3
 template <int MODEL, bool HAS_UP, bool LOGF, typename F>
 __device__ __forceinline__ void pixel_accumulate_fast(const PBlock& P, const HuberK& hk, F u, F px, float v, F dux, F duy,
-                                                 F dlat, F cu, F cl, F (&acc)[kNAcc]) {
+                                                 F slat, F cu, F cl, F (&acc)[kNAcc]) {
     constexpr bool DIST = MODEL != GCLM_PINHOLE;
     // u = (x - cx)/fx and px = ga - gc u belong to the lane's COLUMN and are loop invariants of the sweep
     // (column-stationary mapping, see sweep_kernel); v = (y - cy)/fy is lane-scalar (one image row per tile)
@@ -407,7 +434,7 @@ __device__ __forceinline__ void pixel_accumulate_fast(const PBlock& P, const Hub
         const F guv = vfma(u, vsplat(u, P.ga), vsplat(u, v * P.gb));          // g_xy . uv
         const F s = vfma(ern, guv, rnn * P.gc);                              // ray . g
         const F sc = vclamp(s, -1.0f + 1e-6f, 1.0f - 1e-6f);
-        const F rl = sin_halfpi(dlat) - sc;              // lm_optimizer.py:262,270-271
+        const F rl = slat - sc;                          // lm_optimizer.py:262,270-271 (slat = sin(latitude_field))
         const F wgt = huber_accumulate(rl * rl, hk.inv_a2l, cl, acc[A_CL]);
         const F l0 = vfma(ern, vfma(u, vsplat(u, P.T00), vsplat(u, v * P.T10)), rnn * P.T20);   // ray . T[:,0]
         const F l1 = vfma(ern, vfma(u, vsplat(u, P.T01), vsplat(u, v * P.T11)), rnn * P.T21);
@@ -453,11 +480,14 @@ __device__ __forceinline__ void pixel_accumulate_fast(const PBlock& P, const Hub
 // EMIT (scalar instantiation only): instead of accumulating, write per-pixel quantities out --
 //   1: the Jacobian rows of the predicted fields, J_up (2 x PN) = n s^T with n = (-up_y, up_x), J_lat (1 x PN) = l
 //      (gclm_jacobian_fields);   2: the residuals r_up (2), r_lat (1) (gclm_residual_fields).
-template <int MODEL, bool HAS_UP, bool LOGF, typename F, int EMIT = 0>
+// GMODE (simple_divisional): 0 = guarded radial terms; 1 = guard-free terms, recomputed with the guards when the
+// wave-uniform `patch` says a lane of this wave may need them (an if-without-else: the common path carries no copies)
+template <int MODEL, bool HAS_UP, bool LOGF, typename F, int EMIT = 0, int GMODE = 0>
 __device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& hk, F u, F px, float v, F dux, F duy,
-                                                 F dlat, F cu, F cl, F (&acc)[Layout<MODEL>::NACC],
+                                                 F slat, F cu, F cl, F (&acc)[Layout<MODEL>::NACC],
                                                  [[maybe_unused]] float* j_up = nullptr,
-                                                 [[maybe_unused]] float* j_lat = nullptr) {
+                                                 [[maybe_unused]] float* j_lat = nullptr,
+                                                 [[maybe_unused]] bool patch = false) {
     constexpr bool DIST = MODEL != GCLM_PINHOLE;
     constexpr int ND = Layout<MODEL>::ND, PN = Layout<MODEL>::PN;
     const F r2 = vfma(u, u, vsplat(u, v * v));
@@ -469,7 +499,13 @@ __device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& 
         uvw = vfma(u, wx, vsplat(u, v * wy));
     }
     Radial<F> R;
-    radial_terms<MODEL>(P, r2, R);
+    radial_terms<MODEL, F, GMODE == 0>(P, r2, R);
+    if constexpr (GMODE == 1) {
+        if (patch) {
+            asm volatile("; simple_divisional: guarded radial terms" ::: "memory");   // a real branch: never if-converted
+            radial_terms<MODEL, F, true>(P, r2, R);
+        }
+    }
 
     if constexpr (HAS_UP) {
         const float py = fmaf(-P.gc, v, P.gb);
@@ -568,7 +604,7 @@ __device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& 
             const F guv = vfma(u, vsplat(u, P.ga), vsplat(u, v * P.gb));
             const F s_ = vfma(trn, guv, rnn * P.gc);
             const F sc = vclamp(s_, -1.0f + 1e-6f, 1.0f - 1e-6f);
-            const F rl = sin_halfpi(dlat) - sc;              // lm_optimizer.py:262,270-271
+            const F rl = slat - sc;                          // lm_optimizer.py:262,270-271 (slat = sin(latitude_field))
             const F wgt = huber_accumulate(rl * rl, hk.inv_a2l, cl, acc[A_CL]);
             F l[PN];
             l[0] = vfma(trn, vfma(u, vsplat(u, P.T00), vsplat(u, v * P.T10)), rnn * P.T20);
@@ -613,7 +649,7 @@ __device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& 
             const F rayx = Px * rnn, rayy = Py * rnn;        // rayz = rnn
             const F s_ = vfma(rayx, vsplat(u, P.ga), vfma(rayy, vsplat(u, P.gb), rnn * P.gc));
             const F sc = vclamp(s_, -1.0f + 1e-6f, 1.0f - 1e-6f);
-            const F rl = sin_halfpi(dlat) - sc;              // lm_optimizer.py:262,270-271
+            const F rl = slat - sc;                          // lm_optimizer.py:262,270-271 (slat = sin(latitude_field))
             const F wgt = huber_accumulate(rl * rl, hk.inv_a2l, cl, acc[A_CL]);
             F l[PN];
             l[0] = vfma(rayx, vsplat(u, P.T00), vfma(rayy, vsplat(u, P.T10), rnn * P.T20));
@@ -705,6 +741,9 @@ struct Lane<4> {
     }
     static __device__ __forceinline__ F get(const V& v, int k) { return k == 0 ? f2{v.x, v.y} : f2{v.z, v.w}; }
     static __device__ __forceinline__ V ones() { return make_float4(1.f, 1.f, 1.f, 1.f); }
+    static __device__ __forceinline__ bool any_zero(F a) { return a.x == 0.f || a.y == 0.f; }
+    static __device__ __forceinline__ float max_of(const F (&t)[2]) { return fmaxf(fmaxf(fmaxf(t[0].x, t[0].y), t[1].x), t[1].y); }
+    static __device__ __forceinline__ F fold(F a) { return f2{fold_halfpi(a.x), fold_halfpi(a.y)}; }
     static __device__ __forceinline__ F xcoord(int x, int k) {
         const float x0 = (float)(x + 2 * k);
         return f2{x0, x0 + 1.0f};
@@ -720,6 +759,9 @@ struct Lane<1> {
     }
     static __device__ __forceinline__ F get(const V& v, int) { return v; }
     static __device__ __forceinline__ V ones() { return 1.f; }
+    static __device__ __forceinline__ bool any_zero(F a) { return a == 0.f; }
+    static __device__ __forceinline__ float max_of(const F (&t)[1]) { return t[0]; }
+    static __device__ __forceinline__ F fold(F a) { return fold_halfpi(a); }
     static __device__ __forceinline__ F xcoord(int x, int) { return (float)x; }
 };
 
@@ -734,9 +776,9 @@ struct Lane<1> {
 // offset advances by a wave-uniform constant, and the loop bookkeeping is one add and one compare (the row-major
 // streaming it replaced spent ~21 of 295 VALU instructions per 4 pixels on these; scripts/isa_stats.py).
 template <int MODEL, bool HAS_UP, bool HAS_UPC, bool HAS_LATC, bool LOGF, int VEC>
-// launch bounds: radial / simple_divisional are held to 168 VGPRs (3 waves per SIMD); the two BASELINE models
-// reach 96 / 128 on their own
-__global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL == GCLM_RADIAL) ? GCLM_RADIAL_WAVES : (VEC == 4 && MODEL > GCLM_RADIAL) ? 3 : (VEC == 4 && MODEL == GCLM_SIMPLE_RADIAL) ? 4 : GCLM_MIN_WAVES) void sweep_kernel(
+// launch bounds: radial / simple_divisional are held to 168 VGPRs (3 waves per SIMD); simple_radial reaches 112 (4 waves)
+// on its own; pinhole is held to 80 (6 waves: the latitude range test of round 3 took it to 82 otherwise)
+__global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL == GCLM_RADIAL) ? GCLM_RADIAL_WAVES : (VEC == 4 && MODEL > GCLM_RADIAL) ? 3 : (VEC == 4 && MODEL == GCLM_SIMPLE_RADIAL) ? 4 : (VEC == 4 && MODEL == GCLM_PINHOLE) ? GCLM_PINHOLE_WAVES : GCLM_MIN_WAVES) void sweep_kernel(
     const SweepArgs a) {
     if (stop_fired_before(a.ctrl, a.stop_step)) return;   // batch-global early stop, no host sync
     constexpr int NACC = Layout<MODEL>::NACC;
@@ -794,6 +836,13 @@ __global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL == GCLM_RADIAL) ? GCLM_R
         col_u[k] = (L::xcoord(xu * VEC, k) - P.cx) * P.ifx;                           // camera.py:309-311
         col_px[k] = vfma(col_u[k], vsplat(col_u[k], -P.gc), vsplat(col_u[k], P.ga));  // p_x = ga - gc u
     }
+    // simple_divisional: can a guarded denominator vanish?  (k: wave-uniform; the column part of r2 == 0: loop invariant)
+    [[maybe_unused]] bool col_zero = false;
+    [[maybe_unused]] const bool div_k_tiny = GCLM_DIV_GUARD_ALWAYS || !(fabsf(P.k1) >= 1e-20f);
+    if constexpr (MODEL == GCLM_SIMPLE_DIVISIONAL) {
+#pragma unroll
+        for (int k = 0; k < L::kPairs; ++k) col_zero = col_zero || L::any_zero(col_u[k]);
+    }
     if (live) {
         for (; y < y_end; y += a.rpi, off += off_step) {
             V vux, vuy, vcu = L::ones(), vcl = L::ones();
@@ -807,6 +856,20 @@ __global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL == GCLM_RADIAL) ? GCLM_R
             // keep every load of the iteration ahead of the math: left alone, the scheduler sinks loads next to
             // their first use to save registers in some instantiations (load -> wait -> use, five times over)
             __builtin_amdgcn_sched_barrier(0);
+            // latitudes beyond +-pi/2 (never from the CNN head; a caller's own field may hold them): fold them into the
+            // polynomial's range.  Wave-uniform branch on a ballot: in-range data pays one max3 / max / cmp per 4 pixels.
+            F slat[L::kPairs];
+            {
+                F lt[L::kPairs], t[L::kPairs];
+#pragma unroll
+                for (int k = 0; k < L::kPairs; ++k) { lt[k] = L::get(vlat, k); t[k] = lt[k] * lt[k]; }
+                if (__builtin_amdgcn_ballot_w64(L::max_of(t) > kHalfPiSq) != 0) {
+#pragma unroll
+                    for (int k = 0; k < L::kPairs; ++k) { lt[k] = L::fold(lt[k]); t[k] = lt[k] * lt[k]; }
+                }
+#pragma unroll
+                for (int k = 0; k < L::kPairs; ++k) slat[k] = sin_halfpi(lt[k], t[k]);
+            }
             const float v = ((float)y - P.cy) * P.ify;
 #if GCLM_NOMATH     // measurement only: the memory-system ceiling of this exact access pattern
 #pragma unroll
@@ -815,16 +878,27 @@ __global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL == GCLM_RADIAL) ? GCLM_R
             (void)v;
             (void)hk;
 #else
+            if constexpr (MODEL == GCLM_SIMPLE_DIVISIONAL) {
+                // a guarded denominator of radial_terms can only vanish on the principal point (r2 == 0: this wave holds
+                // it in this iteration) or for k ~ 0 (the first sweep): only then are the guarded terms computed
+                const bool patch = div_k_tiny || __builtin_amdgcn_ballot_w64(col_zero && v == 0.f) != 0;
 #pragma unroll
-            for (int k = 0; k < L::kPairs; ++k) {
-                if constexpr (MODEL == GCLM_PINHOLE || MODEL == GCLM_SIMPLE_RADIAL)
-                    pixel_accumulate_fast<MODEL, HAS_UP, LOGF, F>(P, hk, col_u[k], col_px[k], v, HAS_UP ? L::get(vux, k) : F(0.f),
-                                                            HAS_UP ? L::get(vuy, k) : F(0.f), L::get(vlat, k),
-                                                            L::get(vcu, k), L::get(vcl, k), acc);
-                else
-                    pixel_accumulate<MODEL, HAS_UP, LOGF, F>(P, hk, col_u[k], col_px[k], v, HAS_UP ? L::get(vux, k) : F(0.f),
-                                                       HAS_UP ? L::get(vuy, k) : F(0.f), L::get(vlat, k), L::get(vcu, k),
-                                                       L::get(vcl, k), acc);
+                for (int k = 0; k < L::kPairs; ++k)
+                    pixel_accumulate<MODEL, HAS_UP, LOGF, F, 0, 1>(P, hk, col_u[k], col_px[k], v, HAS_UP ? L::get(vux, k) : F(0.f),
+                                                                       HAS_UP ? L::get(vuy, k) : F(0.f), slat[k], L::get(vcu, k),
+                                                                       L::get(vcl, k), acc, nullptr, nullptr, patch);
+            } else {
+#pragma unroll
+                for (int k = 0; k < L::kPairs; ++k) {
+                    if constexpr (MODEL == GCLM_PINHOLE || MODEL == GCLM_SIMPLE_RADIAL)
+                        pixel_accumulate_fast<MODEL, HAS_UP, LOGF, F>(P, hk, col_u[k], col_px[k], v, HAS_UP ? L::get(vux, k) : F(0.f),
+                                                                HAS_UP ? L::get(vuy, k) : F(0.f), slat[k],
+                                                                L::get(vcu, k), L::get(vcl, k), acc);
+                    else
+                        pixel_accumulate<MODEL, HAS_UP, LOGF, F>(P, hk, col_u[k], col_px[k], v, HAS_UP ? L::get(vux, k) : F(0.f),
+                                                           HAS_UP ? L::get(vuy, k) : F(0.f), slat[k], L::get(vcu, k),
+                                                           L::get(vcl, k), acc);
+                }
             }
 #endif
         }
@@ -914,7 +988,9 @@ __global__ __launch_bounds__(kBlock) void residual_kernel(const float* up, const
     float acc[NACC];
     const size_t px = (size_t)b * N + i;
     const float dux = up ? up[(size_t)b * 2 * N + i] : 0.f, duy = up ? up[(size_t)b * 2 * N + N + i] : 0.f;
-    const float dl = lat ? lat[px] : 0.f;
+    float dl = lat ? lat[px] : 0.f;
+    if (beyond_halfpi(dl)) dl = fold_halfpi(dl);            // torch.sin of any latitude (lm_optimizer.py:262,270)
+    dl = sin_halfpi(dl);
     const float u = ((float)x - P.cx) * P.ifx, v = ((float)y - P.cy) * P.ify;
     pixel_accumulate<MODEL, true, false, float, 2>(P, hk, u, fmaf(u, -P.gc, P.ga), v, dux, duy, dl, 1.f, 1.f, acc,
                                                    r_up ? r_up + px * 2 : nullptr, r_lat ? r_lat + px : nullptr);

@@ -33,8 +33,18 @@ __device__ inline bool coop_reduce_partials(const float* partials, int B, int nc
     if (b < B && slot < nacc) {
         double d = 0.0;
         const float* p = partials + (size_t)b * nchunks * nacc + slot;
-#pragma unroll 4
-        for (int c = first; c < nchunks; c += stride) d += p[(size_t)c * nacc];
+        // batches of 16 records: all loads of a batch are in flight together (one memory round trip for the 15 records
+        // of a 640x480 image instead of four), summed in ascending chunk order as before (the padding adds exact zeros)
+        for (int c0 = first; c0 < nchunks; c0 += 16 * stride) {
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int c = c0 + j * stride;
+                v[j] = c < nchunks ? p[(size_t)c * nacc] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) d += v[j];
+        }
         sacc[grp][slot] = d;
     }
     __syncthreads();
@@ -138,7 +148,7 @@ __global__ void prep_final_kernel(SolveCtx c) {
     if (b >= c.B) return;
     const State s = c.state[sel][b];
     PBlock p;
-    build_pblock(s, false, false, p);
+    build_pblock(s, false, c.iso_final != 0, p);     // iso_final: log-focal columns, rescaled in finalize_kernel
     c.pb_final[b] = p;
 }
 
@@ -224,6 +234,13 @@ __global__ __launch_bounds__(kGroups * kSlots) void finalize_kernel(SolveCtx c, 
     if (cfg.compute_uncertainty) {
         float A[PM][PM], Gf[PM];
         unpack_system<PM>(acc, A, Gf);
+        if (c.iso_final) {
+            // the final sweep ran the log-focal specialisation (d(u,v)/dlog f = -(u,v)); with fx == fy the plain-focal
+            // column of :481-483 is that column times 1/f  (d(u,v)/df = -(u,v)/f)
+            const float wf = 1.0f / s.fy;
+#pragma unroll
+            for (int i = 0; i < PM; ++i) { A[2][i] *= wf; A[i][2] *= wf; }
+        }
 #pragma unroll
         for (int i = 0; i < PM; ++i)
 #pragma unroll
@@ -323,20 +340,24 @@ __device__ inline void apply_shared_frame(const SolveCtx& c, int step, int b, co
     for (int i = 0; i < NI; ++i) dI[i] = dS[i];
     float Hf[PM][PM], Gf[PM], Dinv[2][2];
     unpack_system<PM>(c.frame_sys + (size_t)b * acc_floats(cfg.camera_model), Hf, Gf);
+    // Everything that decides about the SHARED step is uniform over the frames of the group (the NaN marker of a
+    // non-PD frame block travels in the reduced partials, the Schur solve is the same on every frame): either the
+    // whole group takes dI or nobody does -- one camera per group stays one camera per group.
     ok = frame_block<PM>(Hf, s.lambda, Dinv) && ok;
+    for (int i = 0; i < ni; ++i) ok = ok && fabsf(dI[i]) <= 3.0e38f;     // NaN / inf: a failed step of the group
+    bool frame_failed = false;
     if (ok) {
         float r0 = Gf[0], r1 = Gf[1];
         for (int i = 0; i < ni; ++i) { r0 -= Hf[0][2 + i] * dI[i]; r1 -= Hf[1][2 + i] * dI[i]; }
         dG[0] = Dinv[0][0] * r0 + Dinv[0][1] * r1;
         dG[1] = Dinv[1][0] * r0 + Dinv[1][1] * r1;
-        ok = fabsf(dG[0]) <= 3.0e38f && fabsf(dG[1]) <= 3.0e38f;        // NaN / inf: a failed step
-        for (int i = 0; i < ni; ++i) ok = ok && fabsf(dI[i]) <= 3.0e38f;
-        if (!ok) dG[0] = dG[1] = 0.f;
-    }
-    if (!ok) {
+        // a frame whose OWN back-substitution overflows keeps its gravity and still follows the group's intrinsics
+        frame_failed = !(fabsf(dG[0]) <= 3.0e38f && fabsf(dG[1]) <= 3.0e38f);
+        if (frame_failed) dG[0] = dG[1] = 0.f;
+    } else {
         for (int i = 0; i < kNI; ++i) dI[i] = 0.f;
-        s.fails += 1.f;
     }
+    if (!ok || frame_failed) s.fails += 1.f;
     const V3 gv = grav_update({s.gx, s.gy, s.gz}, dG[0], dG[1], cfg.use_spherical_manifold != 0);
     s.gx = gv.x; s.gy = gv.y; s.gz = gv.z;
     update_focal(s, dI[0], cfg.use_log_focal != 0);
@@ -380,8 +401,13 @@ __global__ __launch_bounds__(kGroups * kSlots) void shared_step_kernel(SolveCtx 
                 const int b = t0 + fl;
                 double d = 0.0;
                 const float* p = c.partials + (size_t)b * c.nchunks * nacc + slot;
-#pragma unroll 4
-                for (int q = 0; q < c.nchunks; ++q) d += p[(size_t)q * nacc];
+                for (int q0 = 0; q0 < c.nchunks; q0 += 16) {          // 16 loads in flight, ascending order (see above)
+                    float v[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) v[j] = q0 + j < c.nchunks ? p[(size_t)(q0 + j) * nacc] : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) d += v[j];
+                }
                 fsys[fl][slot] = (float)d;
                 c.frame_sys[(size_t)b * nacc + slot] = (float)d;
             }

@@ -54,9 +54,16 @@ class _Handle:
     def __init__(self, cfg: _lib.GclmConfig, device: torch.device):
         lib = _lib.load()
         self.ptr = _lib.C.c_void_p()
-        rc = lib.gclm_create(_lib.C.byref(self.ptr), _lib.C.byref(cfg), device.index or 0)
+        assert cfg.device == (device.index or 0)
+        rc = lib.gclm_create(_lib.C.byref(self.ptr), _lib.C.byref(cfg))
         _lib.check(rc, None, "gclm_create")
         self.key = cfg.key()
+        self.device = cfg.device
+
+    def destroy(self):
+        if self.ptr:
+            _lib.load().gclm_destroy(self.ptr)
+            self.ptr = _lib.C.c_void_p()
 
     def configure(self, cfg: _lib.GclmConfig):
         if cfg.key() != self.key:
@@ -209,13 +216,13 @@ class LMOptimizer(nn.Module):
             self.camera_model.num_dist_params() if self.camera_has_distortion else 0)
 
     # ------------------------------------------------------------------ C-ABI plumbing
-    def _config(self) -> _lib.GclmConfig:
+    def _config(self, device_index: int = 0) -> _lib.GclmConfig:
         c = self.conf
         name = self.camera_model.name()
         if name not in _HIP_MODELS:
             raise NotImplementedError(f"camera model `{name}` is not implemented by the HIP path yet "
                                       f"(available: {_HIP_MODELS})")
-        cfg = _lib.GclmConfig()
+        cfg = _lib.GclmConfig.default(device_index)
         cfg.camera_model = _lib.CAMERA_MODEL_IDS[name]
         cfg.shared_intrinsics = int(bool(self.shared_intrinsics))
         cfg.group_size = int(c.group_size or 0)
@@ -244,17 +251,18 @@ class LMOptimizer(nn.Module):
     def _handle(self, device: torch.device, stream: int = None) -> _Handle:
         """The gclm_handle of (device, stream): solves issued from different torch streams (e.g. the CNN of batch k+1
         overlapping the LM of batch k) get different workspaces; the same stream reuses its own, in order."""
-        cfg = self._config()
         idx = device.index if device.index is not None else torch.cuda.current_device()
+        cfg = self._config(idx)
         if stream is None:
             stream = torch.cuda.current_stream(torch.device("cuda", idx)).cuda_stream
         key = (idx, int(stream))
         h = self._handles.pop(key, None)
         if h is None:
             while len(self._handles) >= self._MAX_HANDLES:      # drop the least recently used (its stream may be gone)
-                old = self._handles.pop(next(iter(self._handles)))
-                torch.cuda.synchronize(torch.device("cuda", idx))   # its workspace may still be in flight
-                del old
+                old_key = next(iter(self._handles))
+                old = self._handles.pop(old_key)
+                torch.cuda.synchronize(torch.device("cuda", old_key[0]))   # ITS device: the workspace may still be in flight
+                old.destroy()                                             # explicit: not whenever refcounting allows
             h = _Handle(cfg, torch.device("cuda", idx))
         else:
             h.configure(cfg)

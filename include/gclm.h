@@ -31,7 +31,11 @@
 extern "C" {
 #endif
 
-#define GCLM_VERSION 100
+/* ABI version: bumped whenever struct gclm_config or the export list changes (100 = round 1/2, 300 = round 3:
+ * struct_size / abi_version / device moved into gclm_config, gclm_create lost its third argument, new entry points
+ * gclm_set_sweep_iters, gclm_abi_config_size).  gclm_create refuses a gclm_config whose first two fields do not
+ * carry the library's own sizeof(gclm_config) and GCLM_VERSION, with a message naming both sides. */
+#define GCLM_VERSION 300
 
 /* camera_models of geocalib/camera.py:945-950 */
 enum gclm_camera_model {
@@ -72,6 +76,9 @@ enum gclm_info_slot {
  * setup_optimization_and_priors (lm_optimizer.py:189-246) derives from the priors.
  */
 typedef struct gclm_config {
+    int32_t struct_size;             /* sizeof(gclm_config) of the CALLER's header (set by gclm_default_config) */
+    int32_t abi_version;             /* GCLM_VERSION of the CALLER's header (set by gclm_default_config) */
+    int32_t device;                  /* HIP device ordinal the handle is bound to (LMOptimizer(...).to(device)) */
     int32_t camera_model;            /* enum gclm_camera_model */
     int32_t shared_intrinsics;       /* lm_optimizer.py:147; groups of `group_size` frames */
     int32_t group_size;              /* frames per shared-intrinsics group; 0 = whole batch (reference) */
@@ -94,16 +101,23 @@ typedef struct gclm_config {
 
 typedef struct gclm_handle gclm_handle;
 
-/* Library / ABI version (GCLM_VERSION of the build). */
+/* Library / ABI version (GCLM_VERSION of the build) and the sizeof(gclm_config) the library was built with. */
 int gclm_version(void);
+int gclm_abi_config_size(void);
 
-/* Fill `cfg` with LMOptimizer.default_conf (lm_optimizer.py:144-162), everything estimated, eval mode. */
+/* Fill `cfg` with LMOptimizer.default_conf (lm_optimizer.py:144-162), everything estimated, eval mode, device 0,
+ * and the library's own struct_size / abi_version.  A caller compiled against another header therefore passes the
+ * check of gclm_create only if its struct really has the library's layout: compare gclm_abi_config_size() with the
+ * caller's sizeof(gclm_config) (and gclm_version() with GCLM_VERSION) BEFORE calling this with a smaller struct. */
 int gclm_default_config(gclm_config* cfg);
 
-/* LMOptimizer.__init__ (lm_optimizer.py:164-171): validate the configuration, bind to `device`. */
-int gclm_create(gclm_handle** out, const gclm_config* cfg, int device);
+/* LMOptimizer.__init__ (lm_optimizer.py:164-171): validate the configuration, bind to cfg->device.  Signature as
+ * SURVEY.md section 8(b).  Fails (-5, message via gclm_last_error(NULL)) when cfg->struct_size / cfg->abi_version
+ * are not the library's: a stale caller is told so instead of handing over a too-small struct. */
+int gclm_create(gclm_handle** out, const gclm_config* cfg);
 
-/* Re-configure (set_camera_model :173, .shared_intrinsics, priors) without dropping the workspace. */
+/* Re-configure (set_camera_model :173, .shared_intrinsics, priors) without dropping the workspace.  The device of a
+ * handle cannot change. */
 int gclm_configure(gclm_handle* h, const gclm_config* cfg);
 
 int gclm_destroy(gclm_handle* h);
@@ -273,6 +287,11 @@ int gclm_comm_destroy(gclm_comm* c);
 const char* gclm_comm_last_error(const gclm_comm* c);
 int gclm_comm_all_gather(gclm_comm* c, const float* d_send, float* d_recv, size_t count_per_rank, void* stream);
 int gclm_comm_all_reduce_sum(gclm_comm* c, float* d_buf, size_t count, void* stream);
+
+/* Tuning / test hook (no reference counterpart): loop iterations per workgroup of the sweep (how an image is cut
+ * into partial records; only the summation order depends on it).  0 restores the built-in choice (20, fewer for
+ * small batches).  Replaces the GCLM_SWEEP_ITERS environment variable of rounds 1-2: the solve reads no environment. */
+int gclm_set_sweep_iters(gclm_handle* h, int iters);
 
 /* Timing helper: when enabled, every sweep launch is bracketed by HIP events on the solve's stream;
  * gclm_last_pass_timing waits for the recorded launches, returns their count and summed duration

@@ -45,8 +45,31 @@ def main():
         tail = text[m.end():m.end() + 8000]
         nv = re.search(r"\.amdhsa_next_free_vgpr\s+(\d+)", tail)
         sc = re.search(r"; ScratchSize: (\d+)", text[m.start():m.end() + 6000])
-        a, b = max(loops, key=lambda t: t[1] - t[0])
-        ops = [l.strip().split()[0] for l in body[a:b + 1] if l.startswith("\t") and not l.strip().startswith((".", ";"))]
+        # simple_divisional has TWO row loops (always-guarded for k ~ 0 = the first sweep, guard-free for the rest): the
+        # common one is the loop with fewer v_cndmask; every other model has one big loop
+        bigloops = [t for t in loops if t[1] - t[0] > 100] or loops
+        a, b = min(bigloops, key=lambda t: sum("v_cndmask" in l for l in body[t[0]:t[1] + 1]))
+        other_loops = [sum(1 for l in body[t[0]:t[1] + 1] if l.startswith("\tv_")) for t in bigloops if t != (a, b)]
+        # The loop holds side blocks that a wave only enters in rare cases: the latitude fold (|lat| > pi/2: marked by
+        # v_rndne) and, for simple_divisional, the guarded copy of the body (the one of its two big blocks with MORE
+        # v_cndmask).  Split the loop into basic blocks and count the COMMON path = everything but those.
+        blocks, cur = [], []
+        for l in body[a:b + 1]:
+            if re.match(r"^(\.LBB\d+_\d+):", l) and cur:
+                blocks.append(cur); cur = []
+            if l.startswith("\t") and not l.strip().startswith((".", ";")):
+                cur.append(l.strip().split()[0])
+                if l.strip().startswith(("s_cbranch", "s_branch")):
+                    blocks.append(cur); cur = []
+        if cur:
+            blocks.append(cur)
+        nvalu = lambda ops_: sum(1 for o in ops_ if o.startswith("v_"))  # noqa: E731
+        rare = [i for i, blk in enumerate(blocks) if any(o.startswith("v_rndne") for o in blk)]
+        rare += [i for i, blk in enumerate(blocks) if i not in rare and 20 < nvalu(blk) < 200
+                 and sum(o.startswith("v_cndmask") for o in blk) >= 10]          # the guard patches of simple_divisional
+        ops_all = [o for blk in blocks for o in blk]
+        ops = [o for i, blk in enumerate(blocks) if i not in rare for o in blk]
+        rare_valu = {i: nvalu(blocks[i]) for i in rare}
         c = collections.Counter(ops)
         valu = sum(v for k, v in c.items() if k.startswith("v_"))
         pk = sum(v for k, v in c.items() if k.startswith("v_pk_"))
@@ -54,12 +77,14 @@ def main():
         mov = sum(v for k, v in c.items() if "mov" in k)
         loads = sum(v for k, v in c.items() if k.startswith("global_load"))
         mfma = sum(v for k, v in c.items() if "mfma" in k)
-        results[NAMES[m_id]] = {"loop_instructions": len(ops), "valu": valu, "valu_packed": pk, "valu_transcendental": trans,
+        results[NAMES[m_id]] = {"loop_instructions": len(ops), "loop_instructions_with_rare_blocks": len(ops_all),
+                                "rare_blocks_valu": sorted(rare_valu.values()), "other_loops_valu": other_loops, "cndmask": c.get("v_cndmask_b32_e32", 0) + c.get("v_cndmask_b32_e64", 0),
+                                "valu": valu, "valu_packed": pk, "valu_transcendental": trans,
                                 "valu_mov": mov, "global_loads": loads, "mfma": mfma, "pixels_per_iteration": 4,
                                 "vgprs": int(nv.group(1)) if nv else None, "scratch_bytes": int(sc.group(1)) if sc else None,
                                 "top": c.most_common(12)}
         print(f"{NAMES[m_id]}: loop {len(ops)} instr, VALU {valu} (packed {pk}, trans {trans}, mov {mov}), "
-              f"{loads} global loads, {mfma} mfma -> {valu / 4:.1f} VALU/px; VGPRs {nv.group(1) if nv else '?'}, "
+              f"{loads} global loads, {mfma} mfma -> {valu / 4:.1f} VALU/px; rare blocks (VALU) {sorted(rare_valu.values())}, other loops {other_loops}; VGPRs {nv.group(1) if nv else '?'}, "
               f"scratch {sc.group(1) if sc else '?'} B")
         print("   ", c.most_common(12))
         if dump and dump in m.group(1):

@@ -1,7 +1,8 @@
 """Reference goldens for `simple_divisional` on the draws of the seeded fuzz generator, WITH the reference's own
 sensitivity (build container only: needs /root/reference).
 
-    python tests/golden/make_golden_div.py
+    python tests/golden/make_golden_div.py                 # all SEEDS from scratch
+    python tests/golden/make_golden_div.py 13:300 14:300   # add these (seed:cases) to the existing file
 
 Why: the reference's `SimpleDivisional` Jacobians (camera.py:789-942, flagged "unstable" at :913) cancel
 catastrophically in float32 for small |k| -- the k-column of the Hessian comes out 10-1000x too large and the estimate
@@ -17,7 +18,8 @@ stores
 and the GPU fuzz test gates the HIP path against the REFERENCE where spread <= 1e-3 and only asks for a finite result
 where the reference itself is not reproducible.  `siclib` knobs (loss_fn, init_conf) are not options of the inference
 optimiser (geocalib/lm_optimizer.py:144-162): such draws are left to the oracle.  Seeds: 2024 (the suite's default,
-80 cases) and 11, 12 (the soak of VERDICT r01, 300 cases each)."""
+80 cases), 11, 12 (the soak of VERDICT r01, 300 cases each) and 13..22 (round 3: the other soak seeds, so that no soak
+seed leaves its simple_divisional draws ungated)."""
 import os
 import sys
 
@@ -31,7 +33,7 @@ from conftest import fuzz_draws, result_spread  # noqa: E402
 from oracle import ref_import  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SEEDS = {2024: 80, 11: 300, 12: 300}
+SEEDS = {2024: 80, 11: 300, 12: 300, **{s: 300 for s in range(13, 23)}}
 PER_PIXEL = ("up_field", "latitude_field", "up_confidence", "latitude_confidence")
 
 
@@ -58,7 +60,12 @@ def main():
     ref = ref_import.load()
     torch.set_num_threads(os.cpu_count())
     gold, n, unstable = {}, 0, 0
-    for seed, cases in SEEDS.items():
+    seeds, path = SEEDS, os.path.join(HERE, "golden_div_fuzz.npz")
+    if len(sys.argv) > 1:                                   # incremental: keep what the file already holds
+        seeds = {int(a.split(":")[0]): int(a.split(":")[1]) for a in sys.argv[1:]}
+        with np.load(path) as old:
+            gold = {k: old[k] for k in old.files}
+    for seed, cases in seeds.items():
         for case, model, (H, W), B, data, conf, cams, gravs in fuzz_draws(seed, cases, 4):
             if model != "simple_divisional" or "loss_fn" in conf or "init_conf" in conf:
                 continue
@@ -74,7 +81,7 @@ def main():
             unstable += spread.max() > 1e-3
             print(f"seed {seed} case {case}: {H}x{W} B={B} steps {conf['num_steps']} k_gt {cams[:, 6].round(3)} "
                   f"k_ref {base['camera'][:, 6].round(4)} spread {spread}", flush=True)
-    np.savez_compressed(os.path.join(HERE, "golden_div_fuzz.npz"), **gold)
+        np.savez_compressed(path, **gold)                   # after every seed: an interrupted run keeps its work
     print(f"{n} simple_divisional draws, {unstable} of them not reproducible by the reference itself (spread > 1e-3)")
 
 

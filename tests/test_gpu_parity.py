@@ -826,9 +826,12 @@ def test_result_does_not_depend_on_the_chunking(dev, model, monkeypatch):
     data, _, _ = synth_device(model, 3, 240, 320, dev, seed=5)
     conf = {"camera_model": model, "num_steps": 20, "early_stop": False}
     outs = []
-    for iters in ("2", "7", "20"):
-        monkeypatch.setenv("GCLM_SWEEP_ITERS", iters)
-        outs.append(to_np(LMOptimizer(conf).eval()(data)))
+    from geocalib_amd import _lib
+    for iters in (2, 7, 20):
+        opt = LMOptimizer(conf).eval()
+        h = opt._handle(dev)
+        _lib.check(_lib.load().gclm_set_sweep_iters(h.ptr, iters), h.ptr, "gclm_set_sweep_iters")
+        outs.append(to_np(opt(data)))
     for o in outs[1:]:
         assert np.abs(o["camera"][:, 2:4] / outs[0]["camera"][:, 2:4] - 1).max() < 2e-6
         assert np.abs(o["gravity"] - outs[0]["gravity"]).max() < 2e-6
