@@ -62,6 +62,12 @@ def parse():
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="images for the CPU baseline (-1: auto, 0: skip)")
     ap.add_argument("--no-timing", action="store_true", help="skip the in-library HIP-event timing of the sweeps")
+    ap.add_argument("--comm", default="torch", choices=["torch", "rccl"],
+                    help="route of the two data-path collectives: torch.distributed (nccl = RCCL) or RCCL directly behind "
+                         "the C ABI (gclm_comm_all_gather / gclm_comm_all_reduce_sum on the solve's stream)")
+    ap.add_argument("--virtual-world", type=int, default=0,
+                    help="with --shared-group: give every rank the per-rank shape of a run on this many GPUs (e.g. 8: "
+                         "2 frames of each of batch/2 groups) -- configs[4]'s partition at shape on fewer GPUs")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo (+ ranks sharing GPUs) only to exercise the N>1 path on one GPU")
     return ap.parse_args()
@@ -146,7 +152,8 @@ def main():
 
     ensure_built(local_rank)
     from geocalib_amd import LMOptimizer, _lib
-    from geocalib_amd.parallel import CollectiveTimer, GatherPlan, SharedIntrinsicsSplit, calibrate_sharded
+    from geocalib_amd.parallel import (CollectiveTimer, GatherPlan, RcclComm, SharedIntrinsicsSplit, calibrate_sharded,
+                                       frame_split_layout)
     from geocalib_amd.synth import synth_fields
 
     lib = _lib.load()
@@ -154,6 +161,11 @@ def main():
     n_total = B * world
     gs = args.shared_group
     conf = {"camera_model": args.camera_model, "num_steps": args.lm_steps, "early_stop": False}
+    comm = None
+    if args.comm == "rccl":
+        assert distributed and args.backend == "nccl", "--comm rccl needs a process group to hand out the unique id"
+        comm = RcclComm.from_torch_group(local_dev)
+    vworld = args.virtual_world or world
     if gs == 0:
         # independent intrinsics: rank r owns the contiguous images [r*B, (r+1)*B)
         data, gt_cam, gt_grav = synth_fields(args.camera_model, B, H, W, dev, seed=args.seed, first_index=rank * B)
@@ -162,7 +174,7 @@ def main():
         plan = GatherPlan(n_total, world, dev) if distributed else None      # exchange buffers live outside the timed loop
 
         def step():
-            return calibrate_sharded(opt, data, n_total, plan=plan, timer=ctimer)
+            return calibrate_sharded(opt, data, n_total, comm=comm, plan=plan, timer=ctimer)
     elif args.shared_by_group:
         # shared intrinsics sharded by group: rank r owns the groups of the frames [r*B, (r+1)*B); no collective in the solve
         assert B % gs == 0, "the per-GPU batch must hold whole groups"
@@ -172,22 +184,22 @@ def main():
         plan = GatherPlan(n_total, world, dev) if distributed else None
 
         def step():
-            return calibrate_sharded(opt, data, n_total, plan=plan, timer=ctimer)
+            return calibrate_sharded(opt, data, n_total, comm=comm, plan=plan, timer=ctimer)
     else:
-        # shared intrinsics: n_total/gs groups; every rank holds gs/world frames of EVERY group
-        assert gs % world == 0 and B % (gs // world) == 0, "group size must be divisible by the number of GPUs"
-        fpg = gs // world                                   # frames per group on this rank
-        n_groups = B // fpg
-        data, gt_cam, gt_grav = synth_fields(args.camera_model, B, H, W, dev, seed=args.seed, first_index=rank * fpg,
-                                             group_size=gs, run=fpg, run_stride=gs)
-        opt = LMOptimizer({**conf, "shared_intrinsics": True, "group_size": gs}).eval()
+        # shared intrinsics: every rank holds gs/world frames of EVERY group (--virtual-world: the shape of a larger run)
+        lay = frame_split_layout(B, gs, vworld, rank)
+        fpg, n_groups = lay["fpg"], lay["n_groups"]
+        data, gt_cam, gt_grav = synth_fields(args.camera_model, B, H, W, dev, seed=args.seed, first_index=lay["first_index"],
+                                             group_size=gs, run=lay["run"], run_stride=lay["run_stride"])
+        # one handle solves what it holds: groups of fpg local frames (= the whole group when it is not split)
+        opt = LMOptimizer({**conf, "shared_intrinsics": True, "group_size": fpg}).eval()
         ctimer = CollectiveTimer()
         if not distributed:
             def step():
                 return opt(data)
         else:
             gof = torch.arange(B, device=dev, dtype=torch.int32) // fpg
-            split = SharedIntrinsicsSplit(opt, n_groups, timer=ctimer)
+            split = SharedIntrinsicsSplit(opt, n_groups, comm=comm, timer=ctimer)
 
             def step():
                 return split(data, gof)
@@ -252,7 +264,9 @@ def main():
             "config": {"workload": (f"BASELINE configs[{1 if world == 1 else 2}]: batch={B}/GPU ({n_total} total) "
                                     if gs == 0 else
                                     f"BASELINE configs[4] shape: shared intrinsics, {n_total // gs} groups x {gs} frames "
-                                    f"({B} frames/GPU), ") +
+                                    f"({B} frames/GPU), " if vworld == world or args.shared_by_group else
+                                    f"BASELINE configs[4] per-rank shape of a {vworld}-GPU run: {B * vworld // gs} groups x {gs} frames, "
+                                    f"this rank holds {gs // vworld} frames of each ({B} frames/GPU), ") +
                                    f"synthetic {W}x{H} perspective fields, {args.camera_model}, "
                                    f"{args.lm_steps} LM iters + final/uncertainty sweep, early_stop=False",
                        "shared_group": gs,
@@ -272,7 +286,10 @@ def main():
                 "collectives_per_step": 1 if gs == 0 or args.shared_by_group else args.lm_steps,
                 "collective_bytes": (n_total * 4 * (8 + 3 + _lib.INFO_STRIDE) if gs == 0 or args.shared_by_group
                                      else (n_total // gs) * 4 * _lib.SHARED_PARTIAL_STRIDE),
-                "collective_ms": round(coll_ms_max, 4), "backend": args.backend}
+                "collective_ms": round(coll_ms_max, 4), "backend": args.backend,
+                "comm": ("gclm_comm_* (RCCL behind the C ABI, on the solve's stream)" if comm is not None
+                         else "torch.distributed"),
+                "virtual_world": vworld if vworld != world else None}
         if sweep_n:
             avg_ms = sweep_ms / sweep_n
             achieved = algo_bytes_per_launch / (avg_ms * 1e-3) / 1e9
@@ -286,6 +303,8 @@ def main():
             result["roofline"] = {
                 "bound": "hbm", "kernel": "gclm::sweep_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command, committed; not "
+                                  "re-measured in this run)" if traffic is not None else None,
                 "algorithmic_bytes_per_launch": algo_bytes_per_launch, "avg_launch_ms": round(avg_ms, 4),
                 "launches_timed": sweep_n,
                 "whole_job_frac": round(value / world * (args.lm_steps + 1) * H * W * PLANES * 4 / 1e9 / HBM_PEAK_GBS, 4)}

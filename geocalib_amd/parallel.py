@@ -35,6 +35,25 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def frame_split_layout(frames_per_rank: int, group_size: int, world: int, rank: int) -> Dict[str, int]:
+    """BASELINE configs[4]'s partition ("512 groups x 16 frames ... across 8 GPUs"): every rank holds
+    `group_size // world` frames of EVERY group.  Returns, for `rank`: fpg (frames per group on this rank), n_groups,
+    and the strided index runs of the generator / loader -- local frame b is global frame
+    first_index + (b // run) * run_stride + b % run, its group is b // fpg (= global index // group_size).
+    bench.py and the world-8 CPU test (tests/test_dist.py) share this arithmetic."""
+    if group_size <= 0 or world <= 0 or group_size % world:
+        raise ValueError(f"group_size {group_size} must be a positive multiple of the number of ranks {world}")
+    fpg = group_size // world
+    if frames_per_rank % fpg:
+        raise ValueError(f"{frames_per_rank} frames per rank do not hold whole runs of {fpg} frames per group")
+    return {"fpg": fpg, "n_groups": frames_per_rank // fpg, "first_index": rank * fpg, "run": fpg, "run_stride": group_size}
+
+
+def global_frame_index(b, layout: Dict[str, int]):
+    """Global frame index of local frame(s) `b` under `frame_split_layout` (int or tensor)."""
+    return layout["first_index"] + (b // layout["run"]) * layout["run_stride"] + b % layout["run"]
+
+
 def pack_rows(cam: torch.Tensor, grav: torch.Tensor, info: torch.Tensor) -> torch.Tensor:
     return torch.cat([cam, grav, info], dim=1).contiguous()
 
@@ -156,10 +175,13 @@ class RcclComm:
         if rc != 0:
             raise _lib.GclmError(f"{what} failed ({rc}): {_lib.load().gclm_comm_last_error(self._ptr).decode()}")
 
-    def all_gather(self, send: torch.Tensor) -> torch.Tensor:
-        """(n, k) float32 rows of every rank -> (nranks * n, k), rank order; ONE collective on the current stream."""
+    def all_gather(self, send: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+        """(n, k) float32 rows of every rank -> (nranks * n, k), rank order; ONE collective on the current stream.
+        `out`: a receive buffer kept by the caller (nothing is allocated inside a timed loop)."""
         send = send.contiguous()
-        recv = send.new_empty((self.nranks * send.shape[0],) + tuple(send.shape[1:]))
+        shape = (self.nranks * send.shape[0],) + tuple(send.shape[1:])
+        recv = out if out is not None else send.new_empty(shape)
+        assert recv.is_contiguous() and tuple(recv.shape) == shape and recv.dtype == send.dtype
         s = torch.cuda.current_stream(send.device).cuda_stream
         self._check(_lib.load().gclm_comm_all_gather(self._ptr, send.data_ptr(), recv.data_ptr(), send.numel(), s),
                     "gclm_comm_all_gather")
@@ -201,19 +223,27 @@ def calibrate_sharded(opt: LMOptimizer, local_data: Dict[str, torch.Tensor], n_t
         # no communication and joins the single all-gather.  Frames of ONE group spread over ranks: SharedIntrinsicsSplit.
         gs = opt.conf.group_size
         n_local = next(iter(local_data.values())).shape[0]
-        assert gs and n_local % gs == 0 and n_total % gs == 0, (
-            "calibrate_sharded with shared intrinsics needs `group_size` and whole groups per rank; "
-            "use SharedIntrinsicsSplit when the frames of a group live on several ranks")
-    if opt.conf.early_stop and (comm is not None and comm.nranks > 1 or collectives_on(group)):
+        world_ = comm.nranks if comm is not None else (dist.get_world_size(group) if collectives_on(group) else 1)
+        if not gs or n_local % gs or n_total % gs:
+            raise ValueError("calibrate_sharded with shared intrinsics needs `group_size` and whole groups per rank; "
+                             "use SharedIntrinsicsSplit when the frames of a group live on several ranks")
+        if (n_total // gs) % world_:
+            # shard_range would cut a group in two: say so here, not as a shape error inside the gather
+            raise ValueError(f"{n_total // gs} groups do not divide over {world_} ranks: give every rank the same number "
+                             "of whole groups (or use SharedIntrinsicsSplit)")
+    forced = os.environ.get("GCLM_FORCE_COLLECTIVES") == "1"
+    if opt.conf.early_stop and (comm is not None and (comm.nranks > 1 or forced) or collectives_on(group)):
         # the reference's early stop is ONE decision over the whole batch (lm_optimizer.py:90-92, 619); each rank
         # would take it over its own shard and the gathered result would depend on the world size
         raise ValueError("calibrate_sharded needs early_stop=False (a fixed number of steps): the batch-global early "
                          "stop is not shard-invariant")
     out = opt(local_data)
     rows = pack_rows(*opt._last_raw)
-    if comm is not None and comm.nranks > 1:       # direct RCCL route (equal shards)
+    if comm is not None and (comm.nranks > 1 or forced):       # direct RCCL route (gclm_comm_all_gather; equal shards)
         assert n_total % comm.nranks == 0, "the direct RCCL route expects equal shards"
-        gathered = timer(lambda: comm.all_gather(rows), rows.device) if timer is not None else comm.all_gather(rows)
+        recv = plan.out if plan is not None and plan.out.shape[0] == comm.nranks * rows.shape[0] else None
+        gathered = (timer(lambda: comm.all_gather(rows, recv), rows.device) if timer is not None
+                    else comm.all_gather(rows, recv))
         return infos_from_rows(opt, gathered, "up_field" in local_data)
     if collectives_on(group):
         rows = all_gather_rows(rows, n_total, group, plan, timer)
@@ -280,5 +310,5 @@ class SharedIntrinsicsSplit:
         return out
 
 
-__all__ = ["shard_range", "pack_rows", "unpack_rows", "all_gather_rows", "calibrate_sharded", "GatherPlan",
+__all__ = ["shard_range", "frame_split_layout", "global_frame_index", "pack_rows", "unpack_rows", "all_gather_rows", "calibrate_sharded", "GatherPlan",
            "CollectiveTimer", "SharedIntrinsicsSplit", "RcclComm", "ROW", "BaseCamera"]

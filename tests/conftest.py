@@ -104,10 +104,43 @@ def golden_outputs(setname: str, variant: str) -> dict:
     return {k[len(pre):]: small[k] for k in small.files if k.startswith(pre)}
 
 
+MEASURED = {}      # label -> what compare_result / the fuzz actually measured (written to gpurun_out/ at session end)
+
+
+def measure_result(out: dict, ref: dict) -> dict:
+    """The distances compare_result gates, as numbers (scripts/parity_report.py, profiles/r03_parity.json)."""
+    def rel(a, b):
+        return float(np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
+    cam, rcam = np.asarray(out["camera"]), ref["camera"]
+    m = {"focal": float(np.abs(cam[:, 2:4] / rcam[:, 2:4] - 1).max()), "dist": float(np.abs(cam[:, 6:] - rcam[:, 6:]).max()),
+         "gravity": float(np.abs(np.asarray(out["gravity"]) - ref["gravity"]).max()),
+         "cost": max(rel(out[k], ref[k]) for k in ("initial_cost", "final_cost", "initial_latitude_cost", "final_latitude_cost"))}
+    if "covariance" in ref and "covariance" in out:
+        m["cov"] = rel(out["covariance"], ref["covariance"])
+        m["unc"] = max([rel(out[k], ref[k]) for k in ("roll_uncertainty", "pitch_uncertainty", "gravity_uncertainty",
+                                                      "focal_uncertainty", "vfov_uncertainty") if np.abs(ref[k]).max() > 0] or [0.0])
+    return m
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if MEASURED and os.path.isdir(os.path.join(ROOT, "gpurun_out")) or (MEASURED and os.environ.get("GCLM_PARITY_LOG")):
+        import json
+        path = os.environ.get("GCLM_PARITY_LOG") or os.path.join(ROOT, "gpurun_out", "parity_measured.json")
+        try:
+            old = json.load(open(path)) if os.path.exists(path) else {}
+            old.update(MEASURED)
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            json.dump(old, open(path, "w"), indent=0, sort_keys=True)
+        except Exception:
+            pass
+
+
 def compare_result(out: dict, ref: dict, tol: dict, label: str = ""):
     """Shared parity assertion.  tol: focal (rel), dist/gravity (abs), cost/unc/cov (rel to max)."""
     def rel(a, b):
         return np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30)
+    if label:
+        MEASURED[label] = {**measure_result(out, ref), "tol": {k: float(v) for k, v in tol.items()}}
     cam, rcam = np.asarray(out["camera"]), ref["camera"]
     assert np.array_equal(cam[:, [0, 1, 4, 5]], rcam[:, [0, 1, 4, 5]]), label
     f = np.abs(cam[:, 2:4] / rcam[:, 2:4] - 1).max()

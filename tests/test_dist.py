@@ -91,6 +91,58 @@ def test_shard_ranges_cover_batch():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_all_gather_rows_world8_uneven_8191():
+    """The world size the driver's scaling run uses, with configs[2]'s total minus one image (shards of 1024 and 1023
+    rows, padded to 1024 for the ONE collective): an N=8-only indexing slip must not be hardware's to find."""
+    _run(_gather_worker, 8, 8191)
+
+
+def test_all_gather_rows_world8_even_8192():
+    _run(_gather_worker, 8, 8192)
+
+
+def test_frame_split_layout_covers_every_frame_once():
+    """bench.py's index arithmetic for configs[4] (every rank holds group_size / world frames of EVERY group): over all
+    ranks every global frame is produced exactly once, the local group id equals global index // group_size, and the
+    per-rank shape of the BASELINE run is 512 groups x 2 frames."""
+    import pytest
+    from geocalib_amd.parallel import frame_split_layout, global_frame_index
+    for gs, world, B in ((16, 8, 1024), (16, 2, 64), (16, 1, 32), (8, 4, 6), (16, 16, 5)):
+        seen = []
+        for rank in range(world):
+            lay = frame_split_layout(B, gs, world, rank)
+            assert lay["fpg"] == gs // world and lay["n_groups"] == B // lay["fpg"]
+            b = torch.arange(B)
+            g = global_frame_index(b, lay)
+            assert torch.equal(g // gs, b // lay["fpg"])                 # group_of_frame of bench.py == the global group
+            assert torch.equal(g % gs, rank * lay["fpg"] + b % lay["fpg"])
+            seen.append(g)
+        allg = torch.cat(seen).sort().values
+        assert torch.equal(allg, torch.arange(B * world))                # a partition of the global batch
+    assert frame_split_layout(1024, 16, 8, 3) == {"fpg": 2, "n_groups": 512, "first_index": 6, "run": 2, "run_stride": 16}
+    with pytest.raises(ValueError):
+        frame_split_layout(1024, 16, 3, 0)
+    with pytest.raises(ValueError):
+        frame_split_layout(1023, 16, 8, 0)
+
+
+def _by_group_worker(rank, world):
+    """calibrate_sharded with shared intrinsics says which partition it needs BEFORE any tensor is touched."""
+    import pytest
+    from geocalib_amd import LMOptimizer
+    from geocalib_amd.parallel import calibrate_sharded
+    opt = LMOptimizer({"camera_model": "pinhole", "shared_intrinsics": True, "group_size": 4, "early_stop": False})
+    local = {"latitude_field": torch.zeros(4, 1, 8, 8)}
+    with pytest.raises(ValueError, match="do not divide"):
+        calibrate_sharded(opt, local, 12)             # 3 groups over 2 ranks
+    with pytest.raises(ValueError, match="whole groups"):
+        calibrate_sharded(opt, {"latitude_field": torch.zeros(3, 1, 8, 8)}, 8)
+
+
+def test_calibrate_sharded_validates_group_partition_world2():
+    _run(_by_group_worker, 2)
+
+
 def test_all_gather_rows_world2_uneven():
     _run(_gather_worker, 2, 5)
 

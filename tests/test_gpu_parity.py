@@ -20,9 +20,10 @@ pytestmark = pytest.mark.gpu
 TOL = {"focal": 1e-4, "dist": 1e-4, "gravity": 1e-4, "cost": 1e-4, "cov": 1e-3, "unc": 1e-3}
 HIP_MODELS = ("pinhole", "simple_radial")          # the two BASELINE models: full test matrix
 ALL_MODELS = ("pinhole", "simple_radial", "radial", "simple_divisional")
-# simple_divisional: the reference's own float32 formulas cancel catastrophically (flagged unstable at
-# camera.py:913; the float32 and float64 oracles differ by the same amount, tests/test_oracle.py)
-TOL_DIV = {"focal": 3e-3, "dist": 5e-3, "gravity": 1e-3, "cost": 1e-3, "cov": 2e-2, "unc": 2e-2}
+# simple_divisional: focal / gravity / cost are held to north_star's 1e-4 like every other model.  Named exceptions:
+#   dist 5e-3            the k-column of the reference's Jacobian cancels in float32 (flagged unstable at camera.py:913)
+#   cov / unc 2e-2       the covariance is the inverse of a Hessian whose k row carries that cancellation (camera.py:913)
+TOL_DIV = {**TOL, "dist": 5e-3, "cov": 2e-2, "unc": 2e-2}
 
 
 @pytest.fixture(scope="module")
@@ -104,6 +105,14 @@ def test_hip_matches_reference_full_size_other_models(dev, model, idx):
     assert np.abs(out["covariance"] - ref["covariance"]).max() / np.abs(ref["covariance"]).max() < 1e-3
 
 
+# BASELINE configs[0] restated on the fields of a RANDOM-INIT CNN: the focal is barely observable (its sigma is ~25 % of
+# its value), so rounding in the Hessian moves the optimum along the flat direction.  Named exceptions, everything else
+# at north_star's 1e-4:
+#   focal 1e-3 / cov 5e-2 / unc 2e-2    ill-conditioned problem, not an inaccurate kernel: the reference's own fp32-vs-fp64
+#                                       distance on these fields is of the same size (tests/test_oracle.py, same fixture)
+TOL_CNN = {**TOL, "focal": 1e-3, "dist": 1e-6, "cov": 5e-2, "unc": 2e-2}
+
+
 @pytest.mark.parametrize("variant", ["default", "bench"])
 def test_hip_matches_reference_cnn_fields(dev, variant, oracle):
     """BASELINE configs[0] restated: fields of the reference CNN (seeded random init) on the church image.
@@ -113,8 +122,7 @@ def test_hip_matches_reference_cnn_fields(dev, variant, oracle):
     conf = {} if variant == "default" else {"num_steps": 20, "early_stop": False}
     out = run(conf, data, dev)
     ref = {k.split("/", 1)[1]: g[k] for k in g.files if k.startswith(variant + "/")}
-    compare_result(out, ref, {"focal": 2e-3, "dist": 1e-6, "gravity": 1e-4, "cost": 1e-4, "cov": 5e-2, "unc": 2e-2},
-                   f"cnn/{variant}")
+    compare_result(out, ref, TOL_CNN, f"cnn/{variant}")
     assert np.array_equal(out["stop_at"], ref["stop_at"])
 
 
@@ -128,6 +136,9 @@ def test_hip_follows_reference_step_by_step(dev, setname):
         assert np.abs(out["camera"][:, 2:4] / ref_cam[k - 1][:, 2:4] - 1).max() < 3e-5, k
         assert np.abs(out["camera"][:, 6] - ref_cam[k - 1][:, 6]).max() < 3e-5, k
         assert np.abs(out["gravity"] - ref_grav[k - 1]).max() < 3e-5, k
+
+
+TOL_SYSTEM_DIV_K = 3e-3      # single-sweep system, simple_divisional, k row / column only (camera.py:913)
 
 
 @pytest.mark.parametrize("model", ALL_MODELS)
@@ -144,10 +155,18 @@ def test_hip_single_sweep_system(dev, model, mode):
     out = to_np(opt.system(to_dev(data, dev), cam, grav, as_rpf=(mode == "rpf")))
     Hr, Gr = s[f"{model}/{mode}/H"], s[f"{model}/{mode}/G"]
     d = np.sqrt(np.abs(np.einsum("bii->bi", Hr)))
-    tol = 3e-3 if model == "simple_divisional" else 5e-5
-    assert (np.abs(out["H"] - Hr) / (d[:, :, None] * d[:, None, :])).max() < tol
+    # 5e-5 of the natural scale of each entry.  Named exception: simple_divisional's k row / column (index 3), whose
+    # reference formulas cancel in float32 (camera.py:913) -- the other rows of that model keep the common gate
+    tol = np.full(Hr.shape[1], 5e-5)
+    if model == "simple_divisional":
+        tol[3] = TOL_SYSTEM_DIV_K
+    from conftest import MEASURED
+    eh = (np.abs(out["H"] - Hr) / (d[:, :, None] * d[:, None, :])).max(0)
     cost = (s[f"{model}/{mode}/cost_up"] + s[f"{model}/{mode}/cost_lat"]) * data["latitude_field"][0].size
-    assert (np.abs(out["G"] - Gr) / (d * np.sqrt(cost)[:, None])).max() < tol
+    eg = (np.abs(out["G"] - Gr) / (d * np.sqrt(cost)[:, None])).max(0)
+    MEASURED[f"system/{model}/{mode}"] = {"H_rows": eh.max(1).tolist(), "G": eg.tolist()}
+    assert (eh < np.maximum(tol[:, None], tol[None, :])).all(), eh
+    assert (eg < tol).all(), eg
     assert np.allclose(out["cost_up"], s[f"{model}/{mode}/cost_up"], rtol=2e-5)
     assert np.allclose(out["cost_lat"], s[f"{model}/{mode}/cost_lat"], rtol=2e-5)
 
@@ -165,6 +184,12 @@ def test_hip_matches_oracle_odd_shapes(dev, oracle, model, shape):
     ref = oracle.solve(data, conf, precision="f32")
     out = run(conf, data, dev)
     tol = dict(TOL_DIV if model == "simple_divisional" else TOL)
+    if model == "simple_divisional":
+        # the oracle is ANOTHER float32 evaluation of the reference's cancelling formulas (camera.py:913): it is only as
+        # sharp a yardstick as it agrees with its own float64 build on these inputs
+        from conftest import result_spread
+        own = result_spread(ref, oracle.solve(data, conf, precision="f64"))
+        tol.update(focal=1e-4 + 10 * own[0], gravity=1e-4 + 10 * own[1], dist=5e-3 + 10 * own[2], cost=1e-4 + 10 * own[3])
     if H * W < 100:
         tol.update(focal=5e-3, dist=5e-3, gravity=5e-3, cost=5e-3, cov=1e-1, unc=1e-1)   # 35 pixels: ill-posed
     compare_result(out, ref, tol, f"{model}/{shape}")
@@ -406,66 +431,182 @@ def test_full_size_batch_properties(dev, oracle, model):
     compare_result({k: v[idx] for k, v in a.items()}, ref, TOL, f"B1024/{model}")
 
 
-@pytest.mark.parametrize("split", ["interleaved", "empty_rank"])
-@pytest.mark.parametrize("model", HIP_MODELS)
-def test_split_protocol_two_virtual_ranks(dev, model, split):
-    """BASELINE configs[4] protocol on ONE device: the frames of every group are dealt to two handles
-    ("ranks"); per LM step both reduce their local Schur partials, the partial buffers are summed (what the
-    RCCL all-reduce does), both apply.  Must equal the single-handle shared-intrinsics solve."""
+def run_virtual_ranks(dev, conf, data, selections, gofs, G, H, W):
+    """The split protocol of BASELINE configs[4] on ONE device: rank r = its own LMOptimizer / gclm_handle holding the
+    frames `selections[r]` (indices into `data`, sorted by group) with local group ids `gofs[r]`.  Per LM step every
+    rank reduces its frames to Schur partials (gclm_shared_reduce), the buffers are summed (what the RCCL all-reduce
+    does) and every rank applies (gclm_shared_apply).  Returns per rank (cam, grav, info) as numpy."""
     from geocalib_amd import LMOptimizer, _lib, get_trivial_estimation
     lib = _lib.load()
-    G, gs, H, W = 6, 8, 48, 64
-    data, gtc, gtg = synth_device(model, G * gs, H, W, dev, seed=3, group_size=gs)
-    conf = {"camera_model": model, "num_steps": 12, "early_stop": False, "shared_intrinsics": True, "group_size": gs}
-    single = to_np(LMOptimizer(conf).eval()(data))
-    frames = torch.arange(G * gs, device=dev)
     ranks = []
-    for r in range(2):
-        if split == "interleaved":
-            sel = frames[(frames % gs) // (gs // 2) == r]             # rank r: frames [r*gs/2, (r+1)*gs/2) of each group
-            gof = (torch.arange(sel.numel(), device=dev, dtype=torch.int32) // (gs // 2)).contiguous()
-        else:                                                         # rank 1 holds NO frame: it only joins the all-reduce
-            sel = frames if r == 0 else frames[:0]
-            gof = (sel // gs).to(torch.int32).contiguous()
+    for sel, gof in zip(selections, gofs):
         local = {k: v[sel].contiguous() for k, v in data.items()}
         opt = LMOptimizer(conf).eval()
         cam0, grav0 = get_trivial_estimation(local, opt.camera_model)
         opt.setup_optimization_and_priors(local, shared_intrinsics=True)
         up, lat, upc, latc, (B, _, _) = opt._fields(local)
         h = opt._handle(dev)
-        st = dict(opt=opt, h=h, sel=sel, cam=cam0._data.clone(), grav=grav0._data.clone(), keep=(up, lat, upc, latc),
-                  gof=gof if gof.numel() else torch.zeros(1, device=dev, dtype=torch.int32),
-                  part=torch.zeros((G, _lib.SHARED_PARTIAL_STRIDE), device=dev), info=torch.empty((B, _lib.INFO_STRIDE), device=dev))
         keep_alive = torch.zeros(16, device=dev)                     # an empty tensor has a null data_ptr
+        st = dict(opt=opt, h=h, sel=sel, cam=cam0._data.clone(), grav=grav0._data.clone(), keep=(up, lat, upc, latc),
+                  gof=gof.to(torch.int32).contiguous() if gof.numel() else torch.zeros(1, device=dev, dtype=torch.int32),
+                  part=torch.zeros((G, _lib.SHARED_PARTIAL_STRIDE), device=dev),
+                  info=torch.empty((B, _lib.INFO_STRIDE), device=dev), keep_alive=keep_alive)
         ptr = lambda t: t.data_ptr() if t.numel() else keep_alive.data_ptr()  # noqa: E731
-        st["keep_alive"] = keep_alive
         _lib.check(lib.gclm_shared_begin(h.ptr, ptr(up), ptr(lat), ptr(upc), ptr(latc), B, H, W,
                                          ptr(st["cam"]), ptr(st["grav"]), st["gof"].data_ptr(), G, None), h.ptr)
         ranks.append(st)
     for step in range(conf["num_steps"]):
         for st in ranks:
             _lib.check(lib.gclm_shared_reduce(st["h"].ptr, step, st["part"].data_ptr(), None), st["h"].ptr)
-        total = ranks[0]["part"] + ranks[1]["part"]                    # the all-reduce
+        total = torch.stack([st["part"] for st in ranks]).sum(0)      # the all-reduce
         for st in ranks:
             st["part"].copy_(total)
             _lib.check(lib.gclm_shared_apply(st["h"].ptr, step, st["part"].data_ptr(), None), st["h"].ptr)
     for st in ranks:
         _lib.check(lib.gclm_shared_finish(st["h"].ptr, st["info"].data_ptr() or st["keep_alive"].data_ptr(), None), st["h"].ptr)
     torch.cuda.synchronize()
-    for st in ranks:
-        sel = st["sel"].cpu().numpy()
+    return [(st["cam"].cpu().numpy(), st["grav"].cpu().numpy(), st["info"].cpu().numpy(), st["opt"]) for st in ranks]
+
+
+@pytest.mark.parametrize("split", ["interleaved", "empty_rank"])
+@pytest.mark.parametrize("model", HIP_MODELS)
+def test_split_protocol_two_virtual_ranks(dev, model, split):
+    """BASELINE configs[4] protocol on ONE device: the frames of every group are dealt to two handles
+    ("ranks"); per LM step both reduce their local Schur partials, the partial buffers are summed (what the
+    RCCL all-reduce does), both apply.  Must equal the single-handle shared-intrinsics solve."""
+    from geocalib_amd import LMOptimizer, _lib
+    G, gs, H, W = 6, 8, 48, 64
+    data, gtc, gtg = synth_device(model, G * gs, H, W, dev, seed=3, group_size=gs)
+    conf = {"camera_model": model, "num_steps": 12, "early_stop": False, "shared_intrinsics": True, "group_size": gs}
+    single = to_np(LMOptimizer(conf).eval()(data))
+    frames = torch.arange(G * gs, device=dev)
+    sels, gofs = [], []
+    for r in range(2):
+        if split == "interleaved":
+            sel = frames[(frames % gs) // (gs // 2) == r]             # rank r: frames [r*gs/2, (r+1)*gs/2) of each group
+            gof = torch.arange(sel.numel(), device=dev, dtype=torch.int32) // (gs // 2)
+        else:                                                         # rank 1 holds NO frame: it only joins the all-reduce
+            sel = frames if r == 0 else frames[:0]
+            gof = (sel // gs).to(torch.int32)
+        sels.append(sel); gofs.append(gof)
+    res = run_virtual_ranks(dev, conf, data, sels, gofs, G, H, W)
+    for (cam, grav, info, _), sel in zip(res, sels):
+        sel = sel.cpu().numpy()
         if sel.size == 0:
             continue
-        assert np.abs(st["cam"].cpu().numpy()[:, 2:4] / single["camera"][sel, 2:4] - 1).max() < 2e-6
-        assert np.abs(st["cam"].cpu().numpy()[:, 6] - single["camera"][sel, 6]).max() < 2e-6
-        assert np.abs(st["grav"].cpu().numpy() - single["gravity"][sel]).max() < 2e-6
-        assert np.allclose(st["info"][:, _lib.INFO["final_cost"]].cpu().numpy(), single["final_cost"][sel], rtol=1e-5)
+        assert np.abs(cam[:, 2:4] / single["camera"][sel, 2:4] - 1).max() < 2e-6
+        assert np.abs(cam[:, 6] - single["camera"][sel, 6]).max() < 2e-6
+        assert np.abs(grav - single["gravity"][sel]).max() < 2e-6
+        assert np.allclose(info[:, _lib.INFO["final_cost"]], single["final_cost"][sel], rtol=1e-5)
     if split == "empty_rank":       # rank 0 did everything: the protocol IS the single-device solve, bit for bit
-        assert np.array_equal(ranks[0]["cam"].cpu().numpy(), single["camera"])
-        assert np.array_equal(ranks[0]["grav"].cpu().numpy(), single["gravity"])
+        assert np.array_equal(res[0][0], single["camera"])
+        assert np.array_equal(res[0][1], single["gravity"])
     # one focal per group
     f = single["camera"][:, 3].reshape(G, gs)
     assert np.abs(f / f[:, :1] - 1).max() < 1e-6
+
+
+@pytest.mark.parametrize("model", HIP_MODELS)
+def test_configs4_partition_on_eight_virtual_ranks_matches_reference(dev, model):
+    """BASELINE configs[4]'s ACTUAL partition against the REFERENCE: 16-frame shared-intrinsics groups at 640x480 whose
+    frames are split over 8 ranks (2 frames of every group per rank, `group_of_frame` = [0, 0, 1, 1]), one sum of the
+    Schur partials per LM step.  Every rank's frames must match the reference's own solve of the whole group
+    (tests/golden/golden_shared16.npz; lm_optimizer.py:350-383, 597-603) within north_star's 1e-4."""
+    from geocalib_amd.parallel import frame_split_layout, global_frame_index
+    g = np.load(os.path.join(GOLDEN, "golden_shared16.npz"))
+    data_np, parts = _shared16(model, (0, 1))
+    data = to_dev(data_np, dev)
+    G, gs, world, H, W = 2, 16, 8, 480, 640
+    conf = {"camera_model": model, "shared_intrinsics": True, "group_size": gs, "num_steps": 20, "early_stop": False}
+    sels, gofs = [], []
+    for r in range(world):
+        lay = frame_split_layout(G * gs // world, gs, world, r)          # bench.py's own index arithmetic
+        b = torch.arange(G * gs // world, device=dev)
+        sels.append(global_frame_index(b, lay))
+        gofs.append((b // lay["fpg"]).to(torch.int32))
+    assert torch.equal(torch.cat(sels).sort().values, torch.arange(G * gs, device=dev))
+    res = run_virtual_ranks(dev, conf, data, sels, gofs, G, H, W)
+    cam, grav = np.zeros((G * gs, 8), np.float32), np.zeros((G * gs, 3), np.float32)
+    info = {}
+    for (c, gv, inf, opt), sel in zip(res, sels):
+        sel = sel.cpu().numpy()
+        cam[sel], grav[sel] = c, gv
+        for k, v in opt._unpack_info(torch.from_numpy(inf), True).items():
+            info.setdefault(k, np.zeros((G * gs,) + tuple(v.shape[1:]), np.float32))[sel] = v.numpy()
+    out = {"camera": cam, "gravity": grav, **info}
+    for i in range(G):
+        ref = {k.split("/", 2)[2]: g[k] for k in g.files if k.startswith(f"{model}/g{i}/")}
+        sub = {k: v[gs * i:gs * (i + 1)] for k, v in out.items()}
+        # the covariance of the reference is the one of the per-frame (roll, pitch, focal) system: every rank computes it
+        # for its own frames from the same final estimate
+        compare_result(sub, ref, TOL, f"shared16-split8/{model}/g{i}")
+        assert np.abs(sub["camera"][:, 2:4] - sub["camera"][0, 2:4]).max() == 0      # one camera per group, on every rank
+    assert out["step_failures"].max() == 0
+
+
+@pytest.mark.parametrize("model", HIP_MODELS)
+def test_configs4_per_rank_shape_512_groups_x_2_frames(dev, model):
+    """The per-rank SHAPE of the 8-GPU configs[4] run -- 512 groups, 2 local frames of each, `group_of_frame` with 512
+    distinct values, shared_step_kernel<.., false> over 512 blocks of 2 frames -- on 8 virtual ranks (48x64 frames so
+    that the 8192 frames of the whole job fit comfortably): equal to the single-handle solve of the 512 whole groups."""
+    from geocalib_amd import LMOptimizer
+    from geocalib_amd.parallel import frame_split_layout, global_frame_index
+    G, gs, world, H, W = 512, 16, 8, 48, 64
+    data, gtc, _ = synth_device(model, G * gs, H, W, dev, seed=5, group_size=gs)
+    conf = {"camera_model": model, "num_steps": 10, "early_stop": False, "shared_intrinsics": True, "group_size": gs}
+    single = to_np(LMOptimizer(conf).eval()(data))
+    sels, gofs = [], []
+    for r in range(world):
+        lay = frame_split_layout(G * gs // world, gs, world, r)
+        assert (lay["fpg"], lay["n_groups"]) == (2, 512)
+        b = torch.arange(G * gs // world, device=dev)
+        sels.append(global_frame_index(b, lay))
+        gofs.append((b // lay["fpg"]).to(torch.int32))
+        assert gofs[-1].unique().numel() == 512
+    res = run_virtual_ranks(dev, conf, data, sels, gofs, G, H, W)
+    for (cam, grav, info, _), sel in zip(res, sels):
+        sel = sel.cpu().numpy()
+        assert np.abs(cam[:, 2:4] / single["camera"][sel, 2:4] - 1).max() < 5e-6
+        assert np.abs(cam[:, 6] - single["camera"][sel, 6]).max() < 5e-6
+        assert np.abs(grav - single["gravity"][sel]).max() < 5e-6
+    f = single["camera"][:, 3].reshape(G, gs)
+    assert np.abs(f / f[:, :1] - 1).max() < 1e-6 and np.median(np.abs(f[:, 0] / gtc[::gs, 3].cpu().numpy() - 1)) < 2e-2
+
+
+def test_latitudes_beyond_halfpi_follow_torch_sin(dev):
+    """The reference takes torch.sin of whatever latitude field it is handed (lm_optimizer.py:262, 270); the sweep's
+    polynomial covers [-pi/2, pi/2] and anything beyond is folded into that range first.  Per-pixel residuals against
+    torch.sin in float64 for latitudes up to +-90 (a caller feeding degrees), the fused sweep against the mean of the
+    per-pixel costs (vector path, scalar path), and in-range data is untouched by the fold (bit for bit)."""
+    from geocalib_amd import LMOptimizer
+    from geocalib_amd.lm_optimizer import get_trivial_estimation
+    for W in (64, 50):                                                   # float4 path / scalar-load path
+        data, _, _ = synth_device("simple_radial", 3, 48, W, dev, seed=13)
+        opt = LMOptimizer({"camera_model": "simple_radial"}).eval()
+        cam, grav = get_trivial_estimation(data, opt.camera_model)
+        base = opt.calculate_residuals(cam, grav, data)["latitude_residual"].double()
+        gen = torch.Generator().manual_seed(W)
+        wild = dict(data)
+        off = torch.zeros_like(data["latitude_field"])
+        off[0] = (torch.rand(off[0].shape, generator=gen) * 180 - 90).to(dev)             # "degrees"
+        off[1, :, ::7, ::5] = (torch.randint(-3, 4, off[1, :, ::7, ::5].shape, generator=gen) * np.pi).float().to(dev)
+        off[2, :, 10, 11] = 1.6                                                            # one pixel of one wave
+        wild["latitude_field"] = (data["latitude_field"] + off).contiguous()
+        got = opt.calculate_residuals(cam, grav, wild)["latitude_residual"].double()
+        want = base + (torch.sin(wild["latitude_field"].double()) - torch.sin(data["latitude_field"].double())).reshape(base.shape)
+        assert (got - want).abs().max() < 5e-7, (got - want).abs().max()
+        # the fused sweep (its own fold, behind the wave-uniform branch) agrees with the per-pixel path
+        res = opt.calculate_residuals(cam, grav, wild)
+        costs, _ = opt.calculate_costs(res, wild)
+        sysm = opt.system(wild, cam, grav)
+        assert torch.allclose(costs["latitude_cost"].mean(1), sysm["cost_lat"], rtol=2e-5)
+        assert torch.allclose(costs["up_cost"].mean(1), sysm["cost_up"], rtol=2e-5)
+        # a field shifted by 2 pi everywhere solves to the same calibration
+        shifted = dict(data)
+        shifted["latitude_field"] = data["latitude_field"] + 2 * np.pi
+        conf = {"camera_model": "simple_radial", "num_steps": 20, "early_stop": False}
+        a, b = run_dev(conf, data), run_dev(conf, shifted)
+        assert np.abs(a["camera"][:, 3] / b["camera"][:, 3] - 1).max() < 1e-4 and np.abs(a["gravity"] - b["gravity"]).max() < 1e-4
 
 
 @pytest.mark.parametrize("model", HIP_MODELS)
@@ -534,18 +675,31 @@ def test_rccl_c_abi_single_rank(dev):
     torch.cuda.synchronize()
 
 
+# Per-draw gates of the fuzz: [focal rel, gravity abs, distortion abs, final-cost rel] <= FUZZ_GATE + 10 x (what the
+# yardstick itself moves on that draw).  north_star's 1e-4 on every quantity of every model; named exception:
+#   simple_divisional distortion 5e-3    the reference's k-column cancels in float32 (camera.py:913)
+FUZZ_GATE = {m: np.array([1e-4, 1e-4, 1e-4, 1e-4]) for m in ALL_MODELS}
+FUZZ_GATE["simple_divisional"] = np.array([1e-4, 1e-4, 5e-3, 1e-4])
+# Draws on which the yardstick moves by more than 1e-3 between float32 and float64 (oracle) or under a 1-ulp input
+# perturbation (reference, simple_divisional) cannot gate anything: they only have to stay finite.  Their number is
+# pinned for the committed default seed (so that a regression cannot hide in "undetermined"); other seeds: at most 30 %.
+FUZZ_UNDETERMINED_2024 = {"pinhole": 0, "simple_radial": 0, "radial": 0, "simple_divisional": 0}
+
+
 def test_randomised_configurations_against_oracle(dev, oracle):
     """Seeded fuzz: random shapes (vector and scalar paths), batch sizes, ALL FOUR camera models, conf knobs, missing
     confidences / up field, priors and scales -- the HIP path against the oracle on identical inputs, and for
-    `simple_divisional` against the REFERENCE's own result on that draw (tests/golden/make_golden_div.py), gated by
-    the reference's own reproducibility: where a 1-ulp perturbation of its input moves the reference by more than
-    1e-3 (its float32 k-column cancels for small |k|, camera.py:913) the draw only has to stay finite."""
-    from conftest import fuzz_draws, result_spread
+    `simple_divisional` against the REFERENCE's own result on that draw (tests/golden/make_golden_div.py: seeds 2024 and
+    11..22), gated by the yardstick's own reproducibility.  GCLM_FUZZ_SEED / GCLM_FUZZ_CASES: the soak
+    (scripts/fuzz_soak.sh -> profiles/r03_fuzz_soak.txt)."""
+    from conftest import MEASURED, fuzz_draws, result_spread
     seed = int(os.environ.get("GCLM_FUZZ_SEED", "2024"))                             # soak: GCLM_FUZZ_CASES=300
     n_cases, n_models = int(os.environ.get("GCLM_FUZZ_CASES", "80")), int(os.environ.get("GCLM_FUZZ_MODELS", "4"))
     div_path = os.path.join(GOLDEN, "golden_div_fuzz.npz")
     div = np.load(div_path) if n_models == 4 and os.path.exists(div_path) else None
-    worst, undetermined, against_reference, spent = {}, 0, 0, np.zeros(2)
+    worst, against_reference, spent, failures = {}, 0, np.zeros(2), []
+    undetermined = {m: 0 for m in ALL_MODELS}
+    drawn = {m: 0 for m in ALL_MODELS}
     for case, model, (H, W), B, data, conf, cams, gravs in fuzz_draws(seed, n_cases, n_models):
         t0 = time.perf_counter()
         ref = oracle.solve(data, conf, precision="f32")
@@ -553,41 +707,48 @@ def test_randomised_configurations_against_oracle(dev, oracle):
         t1 = time.perf_counter()
         out = run(conf, data, dev)
         spent += np.array([t1 - t0, time.perf_counter() - t1])
+        drawn[model] += 1
         assert np.array_equal(out["camera"][:, [0, 1, 4, 5]], ref["camera"][:, [0, 1, 4, 5]])
-        assert all(np.isfinite(out[k]).all() for k in ("camera", "gravity", "final_cost"))
+        assert all(np.isfinite(out[k]).all() for k in ("camera", "gravity", "final_cost")), (case, model)
         # unconverged / ill-conditioned draws (few steps, tiny images at the focal clamp, radial k2 on a sliver of an
         # image, noise-free costs ~1e-8) amplify rounding chaotically: where the yardstick itself moves by more than
-        # 1e-3 (oracle: float32 vs float64; reference: 1-ulp input perturbations) the draw only has to stay finite;
-        # elsewhere the gate is tight (plus what the yardstick moves).
-        yard, own = ref, result_spread(ref, ref64)
+        # 1e-3 the draw only has to stay finite; elsewhere the gate is tight (plus what the yardstick moves).
+        yard, own, gate, kind = ref, result_spread(ref, ref64), FUZZ_GATE[model], "oracle"
         if div is not None and model == "simple_divisional" and f"{seed}/{case}/camera" in div.files:
             # the reference's float32 result is the yardstick; it is only as sharp as the reference is reproducible
             # (1-ulp input perturbations) and as its cancelling formulas are accurate in float32 at this draw (the
             # same algorithm in float64 -- a different operation order moves a float32 implementation that far)
             yard = {k: div[f"{seed}/{case}/{k}"] for k in ("camera", "gravity", "final_cost", "initial_cost")}
             own = np.maximum(div[f"{seed}/{case}/spread"], own)
-            against_reference += own.max() <= 1e-3
+            kind = "reference"
         elif model == "simple_divisional":
-            # no reference golden for this (seed, case) (goldens exist for seeds 2024, 11, 12): whether the reference
-            # reproduces itself on this draw is unknown (27 % do not), and the oracle's float32-vs-
-            # float64 distance does not tell (fuzz 11/35: both oracles escape a stall the reference and the HIP path
-            # share; fuzz 14/97: the HIP path stalls at 1.8x the oracle's cost; and LM has no step rejection,
-            # lm_optimizer.py:606-613, so not even "the cost went down" holds).  Without the reference's verdict nothing
-            # beyond the finiteness checked above can be asserted on such a draw.
-            undetermined += 1
-            continue
+            # no reference golden for this draw (another seed, or siclib knobs the inference optimiser does not have):
+            # the oracle is the only yardstick.  It follows the same cancelling formulas in another operation order, so
+            # it can leave (or stay in) a stall the reference and the HIP path share (fuzz 11/35): a
+            # LOOSE gate -- wide enough for that, tight enough to catch a broken kernel -- instead of none
+            gate, kind = np.array([2e-3, 2e-3, 5e-3, 2e-3]), "oracle-loose"
+        rec = {"model": model, "yardstick": kind, "own": own.tolist()}
         if own.max() > 1e-3:
-            undetermined += 1
+            undetermined[model] += 1
+            MEASURED[f"fuzz/{seed}/{case}"] = {**rec, "undetermined": True}
             continue
+        against_reference += kind == "reference"
         worst[case] = result_spread(out, yard)
-        tol = np.array([2e-3, 2e-3, 5e-3, 2e-3]) + 10.0 * own
-        assert (worst[case] < tol).all(), (case, model, (H, W), B, conf, worst[case], tol)
-    assert undetermined <= (0.2 if n_models == 3 else 0.4) * n_cases, undetermined
-    if div is not None and seed in (2024, 11, 12):
+        tol = gate + 10.0 * own
+        MEASURED[f"fuzz/{seed}/{case}"] = {**rec, "spread": worst[case].tolist(), "tol": tol.tolist()}
+        if not (worst[case] < tol).all():
+            failures.append((case, model, (H, W), B, conf, worst[case].tolist(), tol.tolist()))
+    w = np.array(list(worst.values()))
+    print(f"fuzz seed {seed}: {n_cases} draws {drawn}, undetermined {undetermined}, {against_reference} simple_divisional "
+          f"draws gated by the reference, {len(failures)} beyond their gate, median spread {np.median(w, axis=0)}, worst "
+          f"{w.max(axis=0)}, seconds in the oracle {spent[0]:.1f} / in the HIP path {spent[1]:.1f}")
+    assert not failures, failures
+    if seed == 2024 and n_cases == 80 and n_models == 4:
+        assert undetermined == FUZZ_UNDETERMINED_2024, undetermined
+    assert sum(undetermined.values()) <= 0.3 * n_cases, undetermined
+    if div is not None and seed in (2024, *range(11, 23)):
         assert against_reference >= 5, against_reference      # simple_divisional really was drawn and TIGHTLY gated by the reference
-    med = np.median(np.array(list(worst.values())), axis=0)
-    print(f"fuzz: {n_cases} draws, {undetermined} undetermined, {against_reference} simple_divisional draws gated by the "
-          f"reference, median spread {med}, seconds in the oracle {spent[0]:.1f} / in the HIP path {spent[1]:.1f}")
+    med = np.median(w, axis=0)
     assert med[0] < 2e-5 and med[1] < 2e-5 and med[3] < 2e-5, med
 
 
