@@ -250,7 +250,8 @@ def main():
     lo = rank * B if cam.shape[0] == n_total else 0
     f_err = (cam[lo:lo + B, 3] / gt_cam[:, 3] - 1).abs().median().item()
     g_err = (out["gravity"]._data[lo:lo + B] - gt_grav).abs().max(1).values.median().item()
-    assert f_err < 5e-3 and g_err < 5e-3, (f_err, g_err)
+    if os.environ.get("GCLM_BENCH_NO_CHECK") != "1":      # only the -DGCLM_NOMATH=1 measurement build (memory ceiling) skips this
+        assert f_err < 5e-3 and g_err < 5e-3, (f_err, g_err)
 
     if rank == 0:
         value = n_total * args.steps / elapsed

@@ -90,6 +90,7 @@ _SIGNATURES = {
     "gclm_comm_all_gather": (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
     "gclm_comm_all_reduce_sum": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "gclm_set_sweep_iters": (C.c_int, [_P, C.c_int]),
+    "gclm_set_fused_steps": (C.c_int, [_P, C.c_int]),
     "gclm_set_timing": (C.c_int, [_P, C.c_int]),
     "gclm_last_pass_timing": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
 }

@@ -15,6 +15,9 @@
 
 using namespace gclm;
 
+#ifndef GCLM_FUSED_MAX_WORKGROUPS
+#define GCLM_FUSED_MAX_WORKGROUPS 2048     // B * workgroups-per-image up to which an LM step is ONE launch (see use_fused)
+#endif
 #ifndef GCLM_ISO_FINAL
 #define GCLM_ISO_FINAL 1      // A/B switch: 0 = the final sweep always takes the general focal column
 #endif
@@ -37,6 +40,7 @@ struct gclm_handle {
         Geometry geo{};
     } sh;
     int sweep_iters = 0;            // gclm_set_sweep_iters: 0 = built-in choice
+    int fused_mode = -1;            // gclm_set_fused_steps: -1 = built-in choice, 0 = never, 1 = whenever it is valid
     // optional timing of the sweep launches
     bool timing = false;
     std::vector<hipEvent_t> ev;
@@ -115,6 +119,7 @@ int ensure_workspace(gclm_handle* h, int B, int nchunks, int G) {
     const size_t o_state0 = take(sizeof(State) * B), o_state1 = take(sizeof(State) * B);
     const size_t o_pb0 = take(sizeof(PBlock) * B), o_pb1 = take(sizeof(PBlock) * B), o_pbf = take(sizeof(PBlock) * B);
     const size_t o_part = take(sizeof(float) * kNAccMax * (size_t)B * nchunks);
+    const size_t o_part2 = take(sizeof(float) * kNAccMax * (size_t)B * nchunks);     // double buffer of the fused path
     const size_t o_fsys = take(sizeof(float) * kNAccMax * (size_t)B);
     const size_t o_gp = take(sizeof(float) * GCLM_SHARED_PARTIAL_STRIDE * (size_t)(G > 0 ? G : 1));
     const size_t o_ctrl = take(sizeof(Ctrl));
@@ -134,6 +139,7 @@ int ensure_workspace(gclm_handle* h, int B, int nchunks, int G) {
     c.pb[1] = reinterpret_cast<PBlock*>(base + o_pb1);
     c.pb_final = reinterpret_cast<PBlock*>(base + o_pbf);
     c.partials = reinterpret_cast<float*>(base + o_part);
+    c.partials2 = reinterpret_cast<float*>(base + o_part2);
     c.frame_sys = reinterpret_cast<float*>(base + o_fsys);
     c.ctrl = reinterpret_cast<Ctrl*>(base + o_ctrl);
     h->group_partials = reinterpret_cast<float*>(base + o_gp);
@@ -156,7 +162,7 @@ SweepArgs sweep_args(const gclm_handle* h, const float* up, const float* lat, co
     return a;
 }
 
-int timed_sweep(gclm_handle* h, const SweepArgs& a, hipStream_t s) {
+int timed_sweep(gclm_handle* h, const SweepArgs& a, hipStream_t s, const FusedArgs* fused = nullptr) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool timing = h->timing && h->ev_used < 2 * 8192;   // bounded: stop recording silently
     if (timing) {
@@ -170,9 +176,21 @@ int timed_sweep(gclm_handle* h, const SweepArgs& a, hipStream_t s) {
         h->ev_used += 2;
         GCLM_HIP(h, hipEventRecord(e0, s));
     }
-    GCLM_HIP(h, launch_sweep(h->cfg.camera_model, a, s));
+    if (fused) GCLM_HIP(h, launch_fused_step(h->cfg.camera_model, a, *fused, s));
+    else GCLM_HIP(h, launch_sweep(h->cfg.camera_model, a, s));
     if (timing) GCLM_HIP(h, hipEventRecord(e1, s));
     return 0;
+}
+
+// One launch per LM step (gclm_pass.hip: fused_step_kernel) pays when a step is bound by its two dependent launches
+// rather than by the sweep: few workgroups in flight.  It is VALID when the early-stop decision is local to a
+// workgroup (one image) or off, for independent intrinsics on the float4 path.
+bool use_fused(const gclm_handle* h, int B, const Geometry& g) {
+    const gclm_config& c = h->cfg;
+    const bool valid = !c.shared_intrinsics && g.vec == 4 && (B == 1 || !c.early_stop) && B > 0;
+    if (!valid || h->fused_mode == 0) return false;
+    if (h->fused_mode == 1) return true;
+    return (long long)B * g.nchunks <= GCLM_FUSED_MAX_WORKGROUPS;
 }
 
 int check_shapes(gclm_handle* h, const float* lat, int B, int H, int W) {
@@ -322,6 +340,13 @@ int gclm_set_sweep_iters(gclm_handle* h, int iters) {
     return 0;
 }
 
+int gclm_set_fused_steps(gclm_handle* h, int mode) {
+    if (!h) return -1;
+    if (mode < -1 || mode > 1) return fail(h, -3, "gclm_set_fused_steps: mode %d not in {-1, 0, 1}", mode);
+    h->fused_mode = mode;
+    return 0;
+}
+
 int gclm_set_timing(gclm_handle* h, int enabled) {
     if (!h) return -1;
     h->timing = enabled != 0;
@@ -368,6 +393,25 @@ static int run_solve(gclm_handle* h, const float* d_up, const float* d_lat, cons
 
     GCLM_HIP(h, launch_init(c, ia, s));
     const bool es = h->cfg.early_stop != 0;
+    if (use_fused(h, B, geo)) {
+        // init | fused(step) x num_steps | fused(final) | finalize : num_steps + 3 launches, partial records double-buffered
+        float* const part[2] = {c.partials, c.partials2};
+        for (int step = 0; step <= h->cfg.num_steps; ++step) {
+            const bool fin = step == h->cfg.num_steps;
+            SweepArgs a = sweep_args(h, d_up, d_lat, d_up_conf, d_lat_conf, c.pb[0], geo, !fin, 0);
+            a.partials = part[step & 1];
+            FusedArgs f;
+            f.c = c;
+            f.step = step;
+            f.is_final = fin ? 1 : 0;
+            f.partials_in = part[(step + 1) & 1];
+            if (int rc = timed_sweep(h, a, s, &f)) return rc;
+        }
+        SolveCtx cf = c;
+        cf.partials = part[h->cfg.num_steps & 1];        // the final sweep's records
+        GCLM_HIP(h, launch_finalize(cf, d_cam_out, d_grav_out, d_info_out, s));
+        return 0;
+    }
     for (int step = 0; step < h->cfg.num_steps; ++step) {
         const SweepArgs a = sweep_args(h, d_up, d_lat, d_up_conf, d_lat_conf, c.pb[step & 1], geo, true, es ? step : 0);
         if (int rc = timed_sweep(h, a, s)) return rc;

@@ -195,34 +195,38 @@ __device__ inline float total_cost(const float* acc, float invN, bool has_up, fl
     return has_up ? cu + cl : cl;
 }
 
-// lambda rule + batch-global "allclose" bookkeeping shared by every update flavour
-// (lm_optimizer.py:95-106, :90-92, :612-627).  Returns the new prev_cost.
-__device__ inline void cost_bookkeeping(const gclm_config& cfg, Ctrl* ctrl, int step, float total,
-                                        State& s, bool update_lambda) {
+// lambda rule + "allclose" test of one image (lm_optimizer.py:95-106, :90-92, :612-627): returns whether the cost
+// still MOVED at this step (always false at step 0, where nothing is compared); the caller counts it.
+__device__ inline bool cost_rules(const gclm_config& cfg, int step, float total, State& s, bool update_lambda) {
+    bool moved = false;
     if (step > 0) {
         if (update_lambda) {
             const float nl = s.lambda * (total > s.prev_cost ? 10.f : 0.1f);
             s.lambda = fminf(fmaxf(nl, 1e-6f), 1e2f);
         }
         const double diff = fabs((double)total - (double)s.prev_cost);
-        const bool close = diff <= (double)cfg.atol + (double)cfg.rtol * fabs((double)s.prev_cost);
-        if (!close) atomicAdd(&ctrl->notclose[step], 1);
+        moved = !(diff <= (double)cfg.atol + (double)cfg.rtol * fabs((double)s.prev_cost));
     }
     s.prev_cost = total;
+    return moved;
 }
 
-// One LM step of one image from its reduced accumulator record: lambda rule + allclose bookkeeping,
-// damped normal equations over the estimated columns, manifold / focal / distortion update, next
-// parameter block.
+// ... and the batch-global bookkeeping on top of it: every image whose cost moved counts into notclose[step]
+__device__ inline void cost_bookkeeping(const gclm_config& cfg, Ctrl* ctrl, int step, float total,
+                                        State& s, bool update_lambda) {
+    if (cost_rules(cfg, step, total, s, update_lambda)) atomicAdd(&ctrl->notclose[step], 1);
+}
+
+// One LM step of one image from its reduced accumulator record, as pure arithmetic on (s, acc): lambda rule +
+// allclose test, damped normal equations over the estimated columns, manifold / focal / distortion update.
+// `s` is the state at `step` on entry and the state at step + 1 on return; returns whether the cost moved.
 template <int PM>
-__device__ inline void update_image(const SolveCtx& c, int step, int b, const float (&acc)[kNAccMax]) {
-    const gclm_config& cfg = c.cfg;
-    State s = c.state[step & 1][b];
-    const float invN = 1.0f / (float)((size_t)c.H * c.W);
+__device__ inline bool lm_step(const gclm_config& cfg, int H, int W, int step, State& s, const float (&acc)[kNAccMax]) {
+    const float invN = 1.0f / (float)((size_t)H * W);
     float cu, cl;
     const float total = total_cost(acc, invN, true, cu, cl);   // A_CU is 0 without an up field
     if (step == 0) { s.init_cu = cu; s.init_cl = cl; }     // infos["initial_*"] (:585-588)
-    cost_bookkeeping(cfg, c.ctrl, step, total, s, !cfg.fix_lambda);
+    const bool moved = cost_rules(cfg, step, total, s, !cfg.fix_lambda);
 
     // damped normal equations over the estimated columns (lm_optimizer.py:109-137)
     float A[PM][PM], d[PM];
@@ -250,11 +254,56 @@ __device__ inline void update_image(const SolveCtx& c, int step, int b, const fl
     s.gx = g.x; s.gy = g.y; s.gz = g.z;
     update_focal(s, df, cfg.use_log_focal != 0);
     if (cfg.camera_model != GCLM_PINHOLE && cfg.estimate_dist) update_dist(s, cfg.camera_model, dk1, dk2);
+    return moved;
+}
 
+// ... applied to image b of a solve: state / parameter-block double buffers and the early-stop counters.
+template <int PM>
+__device__ inline void update_image(const SolveCtx& c, int step, int b, const float (&acc)[kNAccMax]) {
+    State s = c.state[step & 1][b];
+    if (lm_step<PM>(c.cfg, c.H, c.W, step, s, acc)) atomicAdd(&c.ctrl->notclose[step], 1);
     c.state[(step + 1) & 1][b] = s;
     PBlock p;
-    build_pblock(s, cfg.use_spherical_manifold != 0, cfg.use_log_focal != 0, p);
+    build_pblock(s, c.cfg.use_spherical_manifold != 0, c.cfg.use_log_focal != 0, p);
     c.pb[(step + 1) & 1][b] = p;
+}
+
+// ---------------------------------------------------------------- reduction of the sweep's partial records
+// Sum the workgroup partials of ONE image with the whole 256-thread block (8 groups x 32 slots), in the order the
+// update kernels use: >= kStripeMinChunks records -- 8 stripes of chunks (stripe g: g, g + 8, ...), combined in stripe
+// order; fewer -- one ascending walk.  Double accumulation, fixed order: every caller gets the same bits.  Must be
+// called by all threads of the block; the sums are valid in EVERY thread on return (read back from LDS).
+constexpr int kGroups = 8, kSlots = 32, kStripeMinChunks = 33;
+__device__ inline void reduce_image_partials(const float* image_partials, int nchunks, int nacc, float (&acc)[kNAccMax]) {
+    __shared__ double sacc1[kGroups][kSlots + 1];
+    const int grp = threadIdx.x / kSlots, slot = threadIdx.x % kSlots;
+    const bool striped = nchunks >= kStripeMinChunks;
+    const int first = striped ? grp : 0, stride = striped ? kGroups : 1;
+    if (slot < nacc && (striped || grp == 0)) {
+        double d = 0.0;
+        const float* p = image_partials + slot;
+        for (int c0 = first; c0 < nchunks; c0 += 16 * stride) {
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int c = c0 + j * stride;
+                v[j] = c < nchunks ? p[(size_t)c * nacc] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) d += v[j];
+        }
+        sacc1[grp][slot] = d;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kNAccMax; ++i) {
+        double d = 0.0;
+        if (i < nacc) {
+            if (striped) { for (int g = 0; g < kGroups; ++g) d += sacc1[g][i]; }
+            else d = sacc1[0][i];
+        }
+        acc[i] = (float)d;
+    }
 }
 
 }  // namespace dev

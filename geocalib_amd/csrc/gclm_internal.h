@@ -86,6 +86,9 @@ struct SweepArgs {
     float up_scale, lat_scale;   // Huber scales a (lm_optimizer.py:158-159)
 };
 
+struct SolveCtx;
+struct FusedArgs;
+
 struct Geometry {          // how a sweep is cut into blocks (column-stationary tiles, see gclm_pass.hip)
     int vec, nchunks;
     int wu, cu, nstrips, rpi, rows_per_block, wpt, jobs;
@@ -117,6 +120,7 @@ struct SolveCtx {
     PBlock* pb[2];
     PBlock* pb_final;
     float* partials;
+    float* partials2;           // second half of the double buffer (fused small-batch path)
     float* frame_sys;           // (B, acc_floats(model)) reduced per-frame system (shared mode)
     Ctrl* ctrl;
 };
@@ -131,6 +135,14 @@ struct InitArgs {              // initial estimate: explicit (cam, grav) or triv
     const float* up;            // heuristic initialisation reads three pixels of the fields
     const float* lat;
 };
+// One-launch-per-step variant of the sweep for small batches (gclm_pass.hip: fused_step_kernel)
+struct FusedArgs {
+    SolveCtx c;
+    int step;                   // the launch sweeps theta_step after applying update step-1 (final launch: num_steps)
+    int is_final;               // the uncertainty sweep: (roll, pitch, focal) block, takes over prep_final_kernel
+    const float* partials_in;   // the partial records of the previous launch (the other half of the double buffer)
+};
+hipError_t launch_fused_step(int camera_model, const SweepArgs& a, const FusedArgs& f, hipStream_t s);
 hipError_t launch_init(const SolveCtx& c, const InitArgs& ia, hipStream_t s);
 hipError_t launch_update(const SolveCtx& c, int step, hipStream_t s);
 hipError_t launch_prep_final(const SolveCtx& c, hipStream_t s);

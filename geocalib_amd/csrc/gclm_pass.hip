@@ -776,27 +776,9 @@ struct Lane<1> {
 // offset advances by a wave-uniform constant, and the loop bookkeeping is one add and one compare (the row-major
 // streaming it replaced spent ~21 of 295 VALU instructions per 4 pixels on these; scripts/isa_stats.py).
 template <int MODEL, bool HAS_UP, bool HAS_UPC, bool HAS_LATC, bool LOGF, int VEC>
-// launch bounds: radial / simple_divisional are held to 168 VGPRs (3 waves per SIMD); simple_radial reaches 112 (4 waves)
-// on its own; pinhole is held to 80 (6 waves: the latitude range test of round 3 took it to 82 otherwise)
-__global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL == GCLM_RADIAL) ? GCLM_RADIAL_WAVES : (VEC == 4 && MODEL > GCLM_RADIAL) ? 3 : (VEC == 4 && MODEL == GCLM_SIMPLE_RADIAL) ? 4 : (VEC == 4 && MODEL == GCLM_PINHOLE) ? GCLM_PINHOLE_WAVES : GCLM_MIN_WAVES) void sweep_kernel(
-    const SweepArgs a) {
-    if (stop_fired_before(a.ctrl, a.stop_step)) return;   // batch-global early stop, no host sync
+__device__ __forceinline__ void sweep_body(const SweepArgs& a, const PBlock& P, const int b, const int chunk) {
     constexpr int NACC = Layout<MODEL>::NACC;
-#if GCLM_XCD_REMAP      // A/B switch: each XCD (block id % 8) walks a contiguous eighth of the batch
-    int b = blockIdx.y, chunk = blockIdx.x;
-    {
-        const unsigned total = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
-        if ((total & 7u) == 0) {
-            const unsigned nid = (lin & 7u) * (total >> 3) + (lin >> 3);
-            b = (int)(nid / gridDim.x);
-            chunk = (int)(nid - (unsigned)b * gridDim.x);
-        }
-    }
     const int tid = threadIdx.x;
-#else
-    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
-#endif
-    const PBlock P = a.pb[b];                            // workgroup-uniform -> scalar loads
     HuberK hk;
     hk.a2u = a.up_scale * a.up_scale;
     hk.inv_a2u = 1.0f / hk.a2u;
@@ -924,6 +906,107 @@ __global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL == GCLM_RADIAL) ? GCLM_R
     }
 }
 
+// launch bounds: radial / simple_divisional are held to 168 VGPRs (3 waves per SIMD); simple_radial reaches 112 (4 waves)
+// on its own; pinhole is held to 80 (6 waves: the latitude range test of round 3 took it to 82 otherwise)
+template <int MODEL, bool HAS_UP, bool HAS_UPC, bool HAS_LATC, bool LOGF, int VEC>
+__global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL == GCLM_RADIAL) ? GCLM_RADIAL_WAVES : (VEC == 4 && MODEL > GCLM_RADIAL) ? 3 : (VEC == 4 && MODEL == GCLM_SIMPLE_RADIAL) ? 4 : (VEC == 4 && MODEL == GCLM_PINHOLE) ? GCLM_PINHOLE_WAVES : GCLM_MIN_WAVES) void sweep_kernel(
+    const SweepArgs a) {
+    if (stop_fired_before(a.ctrl, a.stop_step)) return;   // batch-global early stop, no host sync
+#if GCLM_XCD_REMAP      // A/B switch: each XCD (block id % 8) walks a contiguous eighth of the batch
+    int b = blockIdx.y, chunk = blockIdx.x;
+    {
+        const unsigned total = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+        if ((total & 7u) == 0) {
+            const unsigned nid = (lin & 7u) * (total >> 3) + (lin >> 3);
+            b = (int)(nid / gridDim.x);
+            chunk = (int)(nid - (unsigned)b * gridDim.x);
+        }
+    }
+#else
+    const int b = blockIdx.y, chunk = blockIdx.x;
+#endif
+    const PBlock P = a.pb[b];                            // workgroup-uniform -> scalar loads
+    sweep_body<MODEL, HAS_UP, HAS_UPC, HAS_LATC, LOGF, VEC>(a, P, b, chunk);
+}
+
+// ONE launch per LM step for small batches (the interactive B = 1 case of the reference's demo, interactive_demo.py:403):
+// the per-image update of step k-1 -- reduction of that step's partial records, lambda rule, damped Cholesky, manifold
+// update (gclm_device.h: lm_step, the very function update_kernel runs) -- is done REDUNDANTLY in the prologue of every
+// workgroup of sweep k, so an LM step is one launch instead of two and the host issues num_steps + 3 launches instead
+// of 2 num_steps + 4.  Every workgroup of an image computes the same bits (fixed reduction order); workgroup 0 of the
+// image commits the new state and the early-stop counter.  Partial records are double-buffered (launch k reads the
+// records of launch k-1 while it writes its own).  Early stop: this kernel is only used when the decision is local to
+// a workgroup -- B == 1 -- or off (gclm_api.hip: use_fused): the stop fires in the prologue that detects it, nothing is
+// committed, nobody sweeps, and every later launch returns at its first instruction pair.
+// The final launch (is_final) does the same with the last update, then builds the (roll, pitch, focal) block of the
+// uncertainty sweep (prep_final_kernel's job) and sweeps with it.
+template <int MODEL, bool HAS_UP, bool HAS_UPC, bool HAS_LATC, bool LOGF>
+__global__ __launch_bounds__(kBlock) void fused_step_kernel(const SweepArgs a, const FusedArgs f) {
+    using namespace dev;
+    constexpr int PM = Layout<MODEL>::PM, NACC = Layout<MODEL>::NACC;
+    const SolveCtx& c = f.c;
+    const gclm_config& cfg = c.cfg;
+    const int b = blockIdx.y, chunk = blockIdx.x, step = f.step;      // this launch sweeps theta_step (final: theta_final)
+    __shared__ PBlock Ps;
+    __shared__ int go;
+    int stop_j = 0;                                                    // > 0: the stop fired after update stop_j (earlier launch)
+    if (cfg.early_stop) {
+        if (!f.is_final) {
+            // every launch after the one that detected the stop leaves its counter at 0 too (see Ctrl)
+            if (step >= 3 && c.ctrl->notclose[step - 2] == 0) return;
+        } else {
+            for (int j = 1; j <= step - 2; ++j)
+                if (c.ctrl->notclose[j] == 0) { stop_j = j; break; }
+        }
+    }
+    State fin;                                                         // thread 0: the state this launch sweeps at
+    bool commit = false, moved = false, stop_now = false;
+    if (step > 0 && stop_j == 0) {
+        float acc[kNAccMax];
+        reduce_image_partials(f.partials_in + (size_t)b * a.nchunks * NACC, a.nchunks, NACC, acc);
+        if (threadIdx.x == 0) {
+            const State prev = c.state[(step - 1) & 1][b];
+            fin = prev;
+            moved = lm_step<PM>(cfg, c.H, c.W, step - 1, fin, acc);
+            stop_now = cfg.early_stop && step - 1 >= 1 && !moved;     // B == 1: this image IS the batch (:619-625)
+            if (stop_now) fin = prev;                                  // the tentative theta_step is discarded
+            commit = !stop_now;
+        }
+    } else if (threadIdx.x == 0) {
+        fin = c.state[stop_j > 0 ? (stop_j & 1) : 0][b];               // an earlier stop's theta_j, or theta_0 (num_steps == 0)
+    }
+    if (threadIdx.x == 0) {
+        PBlock p;
+        if (f.is_final) build_pblock(fin, false, c.iso_final != 0, p);
+        else build_pblock(fin, cfg.use_spherical_manifold != 0, cfg.use_log_focal != 0, p);
+        Ps = p;
+        go = (f.is_final || !stop_now) ? 1 : 0;
+        if (chunk == 0) {
+            if (commit) {
+                c.state[step & 1][b] = fin;
+                if (moved) atomicAdd(&c.ctrl->notclose[step - 1], 1);
+            }
+            if (f.is_final && b == 0) {                                // what prep_final_kernel leaves for finalize_kernel
+                const int sj = stop_j > 0 ? stop_j : (stop_now ? step - 1 : 0);
+                c.ctrl->stopped = sj > 0 ? 1 : 0;
+                c.ctrl->final_sel = sj > 0 ? (sj & 1) : (step & 1);
+            }
+        }
+    }
+    __syncthreads();
+    if (!go) return;
+    // workgroup-uniform parameter block: LDS -> SGPRs (the sweep addresses it as scalar operands)
+    PBlock P;
+    {
+        const float* src = reinterpret_cast<const float*>(&Ps);
+        float* dst = reinterpret_cast<float*>(&P);
+#pragma unroll
+        for (int i = 0; i < kPBlockFloats; ++i)
+            dst[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, src[i])));
+    }
+    sweep_body<MODEL, HAS_UP, HAS_UPC, HAS_LATC, LOGF, 4>(a, P, b, chunk);
+}
+
 // Per-pixel Jacobian fields of the prediction (perspective_fields.py:323-365), the reference's
 // J_perspective_field as a kernel: one thread per pixel, the parameter block built once per workgroup in LDS.
 // J_up (B,H,W,2,PN), J_lat (B,H,W,1,PN), PN = 3 + #dist.  Not on the solve path (which never materialises these).
@@ -1039,6 +1122,26 @@ hipError_t dispatch(const SweepArgs& a, hipStream_t s) {
 }
 
 template <int MODEL>
+hipError_t dispatch_fused(const SweepArgs& a, const FusedArgs& f, hipStream_t s) {
+    const dim3 grid(a.nchunks, a.B), block(kBlock);
+    const bool up = a.up != nullptr, upc = up && a.upc != nullptr, latc = a.latc != nullptr;
+    const bool logf = a.log_focal != 0 && GCLM_LOGF;
+#define GCLM_LAUNCH(U, UC, LC)                                                                               \
+    do {                                                                                                     \
+        if (logf) hipLaunchKernelGGL((fused_step_kernel<MODEL, U, UC, LC, true>), grid, block, 0, s, a, f);  \
+        else hipLaunchKernelGGL((fused_step_kernel<MODEL, U, UC, LC, false>), grid, block, 0, s, a, f);      \
+    } while (0)
+    if (up) {
+        if (upc) { if (latc) GCLM_LAUNCH(true, true, true); else GCLM_LAUNCH(true, true, false); }
+        else     { if (latc) GCLM_LAUNCH(true, false, true); else GCLM_LAUNCH(true, false, false); }
+    } else {
+        if (latc) GCLM_LAUNCH(false, false, true); else GCLM_LAUNCH(false, false, false);
+    }
+#undef GCLM_LAUNCH
+    return hipGetLastError();
+}
+
+template <int MODEL>
 hipError_t dispatch_model(const SweepArgs& a, hipStream_t s) {
     return a.vec == 4 ? dispatch<MODEL, 4>(a, s) : dispatch<MODEL, 1>(a, s);
 }
@@ -1052,6 +1155,18 @@ hipError_t launch_sweep(int camera_model, const SweepArgs& a, hipStream_t s) {
         case GCLM_SIMPLE_RADIAL: return dispatch_model<GCLM_SIMPLE_RADIAL>(a, s);
         case GCLM_RADIAL: return dispatch_model<GCLM_RADIAL>(a, s);
         case GCLM_SIMPLE_DIVISIONAL: return dispatch_model<GCLM_SIMPLE_DIVISIONAL>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_fused_step(int camera_model, const SweepArgs& a, const FusedArgs& f, hipStream_t s) {
+    if (a.B <= 0) return hipSuccess;
+    if (a.vec != 4) return hipErrorInvalidValue;          // the caller only fuses the float4 path
+    switch (camera_model) {
+        case GCLM_PINHOLE: return dispatch_fused<GCLM_PINHOLE>(a, f, s);
+        case GCLM_SIMPLE_RADIAL: return dispatch_fused<GCLM_SIMPLE_RADIAL>(a, f, s);
+        case GCLM_RADIAL: return dispatch_fused<GCLM_RADIAL>(a, f, s);
+        case GCLM_SIMPLE_DIVISIONAL: return dispatch_fused<GCLM_SIMPLE_DIVISIONAL>(a, f, s);
         default: return hipErrorInvalidValue;
     }
 }

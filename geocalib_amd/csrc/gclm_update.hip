@@ -17,7 +17,6 @@ using namespace dev;
 // walk is a latency chain of hundreds of dependent loads): the block takes ONE image and the 8 groups are
 // stripes of its chunks, combined in stripe order.  The per-image leader then owns the sums.  Returns true for
 // leaders.  Must be called by every thread of the block; launch with reduce_blocks(B, nchunks) blocks.
-constexpr int kGroups = 8, kSlots = 32, kStripeMinChunks = 33;
 __host__ __device__ inline int reduce_images_per_block(int nchunks) { return nchunks >= kStripeMinChunks ? 1 : kGroups; }
 inline int reduce_blocks(int B, int nchunks) {
     const int ipb = reduce_images_per_block(nchunks);

@@ -25,6 +25,19 @@ def _batched(camera: BaseCamera, gravity: Gravity):
     return camera, gravity, h, w
 
 
+def get_horizon_line(camera: BaseCamera, gravity: Gravity, relative: bool = True) -> torch.Tensor:
+    """Heights at which the horizon meets the left and right image border (reference: perspective_fields.py:18-44):
+    the horizon passes through the projection m of the direction R e_z and is tilted by the roll.  `relative`
+    divides by the image height.  One (unbatched or single-element) camera.  (The reference's version cannot run: it
+    indexes the batch dimension it has just added, :29-36; this follows its definition.)"""
+    camera, gravity, _, _ = _batched(camera, gravity)
+    m = (camera.K @ gravity.R)[0, :, 2]                       # K R e_z
+    mx, my = m[0] / m[2], m[1] / m[2]
+    slope = torch.tan(gravity.roll)[0]
+    ends = torch.stack([my + mx * slope, my - (camera.size[0, 0] - mx) * slope])
+    return ends / camera.size[0, 1] if relative else ends
+
+
 def get_up_field(camera: BaseCamera, gravity: Gravity, normalize: bool = True) -> torch.Tensor:
     """Projected up direction per pixel, (..., h, w, 2): p = (a, b) - c (u, v), pushed through the
     distortion differential  s p + (ds/duv . ... ) i.e. q = s p + (off . uv-weighted p)."""

@@ -22,6 +22,31 @@ def deg2rad(deg):
     return deg / 180 * math.pi
 
 
+def skew_symmetric(v: torch.Tensor) -> torch.Tensor:
+    """[v]_x, the (..., 3, 3) cross-product matrix of (..., 3) vectors (reference: geocalib/utils.py:217-229)."""
+    x, y, z = v.unbind(-1)
+    o = torch.zeros_like(x)
+    return torch.stack([torch.stack([o, -z, y], -1), torch.stack([z, o, -x], -1), torch.stack([-y, x, o], -1)], -2)
+
+
+def pitch2rho(pitch: torch.Tensor, f: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
+    """Offset of the horizon from the principal point as a fraction of the image height (geocalib/utils.py:282-284)."""
+    return torch.tan(pitch) * f / h
+
+
+def rho2pitch(rho: torch.Tensor, f: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
+    """Inverse of pitch2rho (geocalib/utils.py:287-289)."""
+    return torch.atan(rho * h / f)
+
+
+def get_device() -> str:
+    """"cuda" (= HIP on ROCm) when a device is visible, else "mps" / "cpu" (geocalib/utils.py:302-309).  The LM path
+    itself only runs on a HIP device; this helper serves callers (the reference's demos) that place their tensors."""
+    if torch.cuda.is_available():
+        return "cuda"
+    return "mps" if torch.backends.mps.is_available() else "cpu"
+
+
 def rad2rotmat(roll: torch.Tensor, pitch: torch.Tensor, yaw: torch.Tensor = None) -> torch.Tensor:
     """Rotation Rz(roll) @ Rx(pitch) @ Ry(yaw) with the reference's sign conventions
     (geocalib/utils.py:232-269)."""

@@ -33,7 +33,7 @@ extern "C" {
 
 /* ABI version: bumped whenever struct gclm_config or the export list changes (100 = round 1/2, 300 = round 3:
  * struct_size / abi_version / device moved into gclm_config, gclm_create lost its third argument, new entry points
- * gclm_set_sweep_iters, gclm_abi_config_size).  gclm_create refuses a gclm_config whose first two fields do not
+ * gclm_set_sweep_iters, gclm_set_fused_steps, gclm_abi_config_size).  gclm_create refuses a gclm_config whose first two fields do not
  * carry the library's own sizeof(gclm_config) and GCLM_VERSION, with a message naming both sides. */
 #define GCLM_VERSION 300
 
@@ -292,6 +292,14 @@ int gclm_comm_all_reduce_sum(gclm_comm* c, float* d_buf, size_t count, void* str
  * into partial records; only the summation order depends on it).  0 restores the built-in choice (20, fewer for
  * small batches).  Replaces the GCLM_SWEEP_ITERS environment variable of rounds 1-2: the solve reads no environment. */
 int gclm_set_sweep_iters(gclm_handle* h, int iters);
+
+/* Small batches (the interactive single-image calibration of the reference's demo, interactive_demo.py:403) run ONE
+ * launch per LM step: the per-image update of step k-1 is done in the prologue of every workgroup of sweep k
+ * (num_steps + 3 launches per solve instead of 2 num_steps + 4; results bit-identical to the two-launch sequence).
+ * mode -1 (default): the library decides (few workgroups in flight); 0: never; 1: whenever it is valid (independent
+ * intrinsics, 16-byte aligned fields of a width divisible by 4, and a single image or early_stop = 0 -- the
+ * batch-global stop of lm_optimizer.py:619-625 is only decidable inside a launch when the batch is one image). */
+int gclm_set_fused_steps(gclm_handle* h, int mode);
 
 /* Timing helper: when enabled, every sweep launch is bracketed by HIP events on the solve's stream;
  * gclm_last_pass_timing waits for the recorded launches, returns their count and summed duration

@@ -204,6 +204,22 @@ def fuzz_draws(seed: int, n_cases: int, n_models: int = 4):
         yield case, model, (H, W), B, data, conf, cams, gravs
 
 
+PER_PIXEL = ("up_field", "latitude_field", "up_confidence", "latitude_confidence")
+
+
+def perturbed(data: dict, rng) -> dict:
+    """Every per-pixel input scaled by (1 +- 2^-23), sign drawn per pixel: one unit in the last place.  How far a
+    float32 solver moves under this is the sharpest any OTHER float32 evaluation of the same algorithm can be held to
+    (the LM loop is discontinuous in rounding noise: the x10 / x0.1 damping rule and the batch-global stop compare costs
+    that agree to the last bit or two, lm_optimizer.py:95-106, 90-92)."""
+    out = dict(data)
+    for k in PER_PIXEL:
+        if k in data:
+            sign = rng.integers(0, 2, data[k].shape).astype(np.float32) * 2 - 1
+            out[k] = (data[k] * (np.float32(1) + sign * np.float32(2.0 ** -23))).astype(np.float32)
+    return out
+
+
 def result_spread(a: dict, b: dict) -> np.ndarray:
     """[focal rel, gravity abs, distortion abs, final-cost rel] distance of two result dicts (fuzz gates)."""
     rel_f = np.abs(a["camera"][:, 2:4] / b["camera"][:, 2:4] - 1).max()

@@ -29,12 +29,11 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from conftest import fuzz_draws, result_spread  # noqa: E402
+from conftest import fuzz_draws, perturbed, result_spread  # noqa: E402
 from oracle import ref_import  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SEEDS = {2024: 80, 11: 300, 12: 300, **{s: 300 for s in range(13, 23)}}
-PER_PIXEL = ("up_field", "latitude_field", "up_confidence", "latitude_confidence")
 
 
 def run(ref, conf, data):
@@ -44,16 +43,6 @@ def run(ref, conf, data):
     res = {k: (v._data if k in ("camera", "gravity") else v).numpy().copy() for k, v in out.items()
            if k in ("camera", "gravity", "final_cost", "initial_cost", "stop_at")}
     return res
-
-
-def perturbed(data, rng):
-    """Every per-pixel input scaled by (1 +- 2^-23): one unit in the last place."""
-    out = dict(data)
-    for k in PER_PIXEL:
-        if k in data:
-            sign = rng.integers(0, 2, data[k].shape).astype(np.float32) * 2 - 1
-            out[k] = (data[k] * (np.float32(1) + sign * np.float32(2.0 ** -23))).astype(np.float32)
-    return out
 
 
 def main():

@@ -37,6 +37,35 @@ def test_conversions():
     assert torch.allclose(R @ R.transpose(-1, -2), torch.eye(3)[None], atol=1e-6)
 
 
+def test_small_utils():
+    """The small public helpers of geocalib/utils.py:217-309 and perspective_fields.get_horizon_line (:18-44) that the
+    reference's demos / viz import: definitions in float64, and against the reference where it is mounted."""
+    from geocalib_amd.utils import get_device, pitch2rho, rho2pitch, skew_symmetric
+    v = torch.tensor([[0.3, -1.2, 2.0], [1.0, 0.5, -0.7]], dtype=torch.float64)
+    w = torch.tensor([[-0.4, 0.9, 0.1], [0.2, 0.2, 2.0]], dtype=torch.float64)
+    S = skew_symmetric(v)
+    assert S.shape == (2, 3, 3) and torch.allclose(S, -S.transpose(-1, -2))
+    assert torch.allclose((S @ w[..., None])[..., 0], torch.linalg.cross(v, w))
+    pitch, f, h = torch.tensor([0.3, -0.5]), torch.tensor([500.0, 320.0]), torch.tensor([480.0, 480.0])
+    assert torch.allclose(rho2pitch(pitch2rho(pitch, f, h), f, h), pitch, atol=1e-6)
+    assert torch.allclose(pitch2rho(pitch, f, h), torch.tan(pitch) * f / h)
+    assert get_device() in ("cuda", "mps", "cpu") and (get_device() == "cuda") == torch.cuda.is_available()
+    # horizon line: a level camera sees it at the principal point's height; roll tilts it around the projected midpoint
+    cam, _ = make("pinhole", B=1)
+    flat = pf.get_horizon_line(cam, Gravity.from_rp(torch.zeros(1, dtype=torch.float64), torch.zeros(1, dtype=torch.float64)))
+    assert torch.allclose(flat, torch.full((2,), 0.5, dtype=torch.float64), atol=1e-9)
+    g = Gravity.from_rp(torch.tensor([0.2], dtype=torch.float64), torch.tensor([0.1], dtype=torch.float64))
+    hl, hl_px = pf.get_horizon_line(cam, g), pf.get_horizon_line(cam, g, relative=False)
+    assert torch.allclose(hl * cam.size[0, 1], hl_px)
+    assert ((hl_px[0] - hl_px[1]) / cam.size[0, 0]).item() == pytest.approx(math.tan(0.2), rel=3e-4)   # slope = tan(roll); Gravity.roll carries the 1e-4 guard of gravity.py:66
+    from oracle import ref_import
+    if ref_import.available():
+        ref = ref_import.load()
+        # (the reference's own get_horizon_line raises an IndexError on every input -- it indexes the batch dimension it
+        # has just added, perspective_fields.py:29-36 -- so only its definition can be followed, not its output)
+        assert torch.allclose(ref.utils.skew_symmetric(v), S) and torch.allclose(ref.utils.pitch2rho(pitch, f, h), pitch2rho(pitch, f, h))
+
+
 def test_gravity_roundtrip_and_update():
     roll, pitch = torch.tensor([0.3, -1.0, 2.8, -2.9]), torch.tensor([0.2, -0.7, 0.5, 1.0])
     g = Gravity.from_rp(roll, pitch)
