@@ -16,7 +16,8 @@
 using namespace gclm;
 
 #ifndef GCLM_FUSED_MAX_WORKGROUPS
-#define GCLM_FUSED_MAX_WORKGROUPS 2048     // B * workgroups-per-image up to which an LM step is ONE launch (see use_fused)
+#define GCLM_FUSED_MAX_WORKGROUPS 512      // B * workgroups-per-image up to which an LM step is ONE launch (see use_fused):
+                                           // measured (profiles/r03_latency.json) -- B = 1: -14 %; B = 4: +-0; B >= 16: slower
 #endif
 #ifndef GCLM_ISO_FINAL
 #define GCLM_ISO_FINAL 1      // A/B switch: 0 = the final sweep always takes the general focal column

@@ -6,6 +6,13 @@
 namespace gclm {
 namespace dev {
 
+// The per-image arithmetic below is compiled into several kernels of two translation units (update_kernel,
+// shared_step_kernel, fused_step_kernel ...) that must produce the SAME BITS (the one-launch-per-step path is checked
+// bit for bit against the two-launch path).  With -ffp-contract=fast the backend decides per inlining context which
+// a * b + c becomes an fma, so contraction is switched off for this header: every operation here is an IEEE operation
+// (the fmas that are wanted are written as fmaf).  Restored at the end of the file -- the per-pixel code keeps it.
+#pragma clang fp contract(off)
+
 constexpr float kPi = 3.14159265358979323846f;
 
 struct V3 { float x, y, z; };
@@ -282,15 +289,17 @@ __device__ inline void reduce_image_partials(const float* image_partials, int nc
     if (slot < nacc && (striped || grp == 0)) {
         double d = 0.0;
         const float* p = image_partials + slot;
-        for (int c0 = first; c0 < nchunks; c0 += 16 * stride) {
-            float v[16];
+        // batches of 32 records per thread: the 19 records of a stripe of a single 640x480 image (150 workgroups) are all
+        // in flight together -- one memory round trip; summed in ascending order (the padding adds exact zeros)
+        for (int c0 = first; c0 < nchunks; c0 += 32 * stride) {
+            float v[32];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < 32; ++j) {
                 const int c = c0 + j * stride;
                 v[j] = c < nchunks ? p[(size_t)c * nacc] : 0.f;
             }
 #pragma unroll
-            for (int j = 0; j < 16; ++j) d += v[j];
+            for (int j = 0; j < 32; ++j) d += v[j];
         }
         sacc1[grp][slot] = d;
     }
@@ -305,6 +314,8 @@ __device__ inline void reduce_image_partials(const float* image_partials, int nc
         acc[i] = (float)d;
     }
 }
+
+#pragma clang fp contract(fast)
 
 }  // namespace dev
 }  // namespace gclm

@@ -51,6 +51,9 @@
 #ifndef GCLM_MIN_WAVES
 #define GCLM_MIN_WAVES 1
 #endif
+#ifndef GCLM_DIV_WAVES
+#define GCLM_DIV_WAVES 3
+#endif
 #ifndef GCLM_PINHOLE_WAVES
 #define GCLM_PINHOLE_WAVES 6
 #endif
@@ -907,9 +910,10 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const PBlock& P, 
 }
 
 // launch bounds: radial / simple_divisional are held to 168 VGPRs (3 waves per SIMD); simple_radial reaches 112 (4 waves)
-// on its own; pinhole is held to 80 (6 waves: the latitude range test of round 3 took it to 82 otherwise)
+// on its own; the log-focal pinhole sweep is held to 80 (6 waves: the latitude range test of round 3 took it to 82
+// otherwise; the general-focal instantiation would spill at 80 and keeps its own 96)
 template <int MODEL, bool HAS_UP, bool HAS_UPC, bool HAS_LATC, bool LOGF, int VEC>
-__global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL == GCLM_RADIAL) ? GCLM_RADIAL_WAVES : (VEC == 4 && MODEL > GCLM_RADIAL) ? 3 : (VEC == 4 && MODEL == GCLM_SIMPLE_RADIAL) ? 4 : (VEC == 4 && MODEL == GCLM_PINHOLE) ? GCLM_PINHOLE_WAVES : GCLM_MIN_WAVES) void sweep_kernel(
+__global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL == GCLM_RADIAL) ? GCLM_RADIAL_WAVES : (VEC == 4 && MODEL > GCLM_RADIAL) ? GCLM_DIV_WAVES : (VEC == 4 && MODEL == GCLM_SIMPLE_RADIAL) ? 4 : (VEC == 4 && MODEL == GCLM_PINHOLE && LOGF) ? GCLM_PINHOLE_WAVES : GCLM_MIN_WAVES) void sweep_kernel(
     const SweepArgs a) {
     if (stop_fired_before(a.ctrl, a.stop_step)) return;   // batch-global early stop, no host sync
 #if GCLM_XCD_REMAP      // A/B switch: each XCD (block id % 8) walks a contiguous eighth of the batch
@@ -962,10 +966,11 @@ __global__ __launch_bounds__(kBlock) void fused_step_kernel(const SweepArgs a, c
     State fin;                                                         // thread 0: the state this launch sweeps at
     bool commit = false, moved = false, stop_now = false;
     if (step > 0 && stop_j == 0) {
+        State prev{};
+        if (threadIdx.x == 0) prev = c.state[(step - 1) & 1][b];      // in flight together with the partial records
         float acc[kNAccMax];
         reduce_image_partials(f.partials_in + (size_t)b * a.nchunks * NACC, a.nchunks, NACC, acc);
         if (threadIdx.x == 0) {
-            const State prev = c.state[(step - 1) & 1][b];
             fin = prev;
             moved = lm_step<PM>(cfg, c.H, c.W, step - 1, fin, acc);
             stop_now = cfg.early_stop && step - 1 >= 1 && !moved;     // B == 1: this image IS the batch (:619-625)

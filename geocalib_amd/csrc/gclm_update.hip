@@ -128,10 +128,20 @@ __global__ void init_kernel(SolveCtx c, InitArgs ia) {
 template <int PM>
 __global__ __launch_bounds__(kGroups * kSlots) void update_kernel(SolveCtx c, int step) {
     if (c.cfg.early_stop && stop_fired_before(c.ctrl, step)) return;          // block-uniform
+    // the leader of an image fetches its state BEFORE the reduction: the load overlaps the partial records' round trip
+    // instead of heading the serial chain behind it
+    const bool striped = reduce_images_per_block(c.nchunks) == 1;
+    const int grp = threadIdx.x / kSlots, pb = striped ? (int)blockIdx.x : (int)blockIdx.x * kGroups + grp;
+    State s{};
+    if (threadIdx.x % kSlots == 0 && (!striped || grp == 0) && pb < c.B) s = c.state[step & 1][pb];
     int b;
     float acc[kNAccMax];
     if (!coop_reduce_partials(c.partials, c.B, c.nchunks, acc_floats(c.cfg.camera_model), b, acc)) return;
-    update_image<PM>(c, step, b, acc);
+    if (lm_step<PM>(c.cfg, c.H, c.W, step, s, acc)) atomicAdd(&c.ctrl->notclose[step], 1);
+    c.state[(step + 1) & 1][b] = s;
+    PBlock p;
+    build_pblock(s, c.cfg.use_spherical_manifold != 0, c.cfg.use_log_focal != 0, p);
+    c.pb[(step + 1) & 1][b] = p;
 }
 
 // Parameter block of the final sweep: (roll, pitch, focal) parametrisation (lm_optimizer.py:481-483).

@@ -707,7 +707,7 @@ def test_randomised_configurations_against_oracle(dev, oracle):
     n_cases, n_models = int(os.environ.get("GCLM_FUZZ_CASES", "80")), int(os.environ.get("GCLM_FUZZ_MODELS", "4"))
     div_path = os.path.join(GOLDEN, "golden_div_fuzz.npz")
     div = np.load(div_path) if n_models == 4 and os.path.exists(div_path) else None
-    worst, against_reference, spent, failures = {}, 0, np.zeros(2), []
+    worst, against_reference, spent, failures, stop_shifts = {}, 0, np.zeros(2), [], []
     undetermined = {m: 0 for m in ALL_MODELS}
     drawn = {m: 0 for m in ALL_MODELS}
     for case, model, (H, W), B, data, conf, cams, gravs in fuzz_draws(seed, n_cases, n_models):
@@ -748,8 +748,11 @@ def test_randomised_configurations_against_oracle(dev, oracle):
             # 619-625): WHICH step it fires at is rounding noise, and rtol = 1e-8 on a locally quadratic cost pins the
             # parameters only to ~sqrt(1e-8) = 1e-4.  A draw on which the HIP path stops at a neighbouring step is
             # compared with the yardstick's trajectory AT THAT STEP (the oracle run for exactly that many steps).
+            # (how far apart the two stops are says nothing: a cost creeping along a flat valley crosses the 1e-8
+            # threshold wherever its last bits let it -- seed 11 case 44, pinhole: step 16 vs 13 -- so the step itself is
+            # only asserted where the reference's goldens pin it, test_hip_matches_reference_small / _full_size)
             hip_stop = int(out["stop_at"][0])
-            assert abs(hip_stop - int(np.asarray(yard["stop_at"]).ravel()[0])) <= 2, (case, model, out["stop_at"], yard["stop_at"])
+            stop_shifts.append(hip_stop - int(np.asarray(yard["stop_at"]).ravel()[0]))
             at = {**conf, "num_steps": hip_stop, "early_stop": False}
             yard = oracle.solve(data, at, precision="f32")
             own = result_spread(yard, oracle.solve(data, at, precision="f64"))
@@ -771,7 +774,7 @@ def test_randomised_configurations_against_oracle(dev, oracle):
             failures.append((case, model, (H, W), B, conf, worst[case].tolist(), tol.tolist()))
     w = np.array(list(worst.values()))
     print(f"fuzz seed {seed}: {n_cases} draws {drawn}, undetermined {undetermined}, {against_reference} simple_divisional "
-          f"draws gated by the reference, {len(failures)} beyond their gate, median spread {np.median(w, axis=0)}, worst "
+          f"draws gated by the reference, {len(stop_shifts)} compared at the HIP path's stop step (shifts {sorted(stop_shifts)}), {len(failures)} beyond their gate, median spread {np.median(w, axis=0)}, worst "
           f"{w.max(axis=0)}, seconds in the oracle {spent[0]:.1f} / in the HIP path {spent[1]:.1f}")
     assert not failures, failures
     if seed == 2024 and n_cases == 80 and n_models == 4:
