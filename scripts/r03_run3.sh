@@ -5,7 +5,8 @@ cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out/r03
 export GCLM_PARITY_LOG=$PWD/gpurun_out/r03/parity_measured.json
 rm -f $GCLM_PARITY_LOG
-timeout 1200 python -m pytest tests -m gpu -q -s 2>&1 | tail -150 > gpurun_out/r03/pytest_gpu.log
+timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
+timeout 1200 python -m pytest tests -m gpu -q -s --timeout 300 2>&1 | tail -150 > gpurun_out/r03/pytest_gpu.log
 tail -12 gpurun_out/r03/pytest_gpu.log
 unset GCLM_PARITY_LOG
 echo "=== soak"
