@@ -8,9 +8,10 @@ namespace dev {
 
 // The per-image arithmetic below is compiled into several kernels of two translation units (update_kernel,
 // shared_step_kernel, fused_step_kernel ...) that must produce the SAME BITS (the one-launch-per-step path is checked
-// bit for bit against the two-launch path).  With -ffp-contract=fast the backend decides per inlining context which
+// bit for bit against the two-launch path).  With contraction on, the backend decides per inlining context which
 // a * b + c becomes an fma, so contraction is switched off for this header: every operation here is an IEEE operation
 // (the fmas that are wanted are written as fmaf).  Restored at the end of the file -- the per-pixel code keeps it.
+// (Needs -ffp-contract=fast-honor-pragmas: plain `fast` ignores this pragma.)
 #pragma clang fp contract(off)
 
 constexpr float kPi = 3.14159265358979323846f;

@@ -8,7 +8,7 @@ mkdir -p gpurun_out
 for V in A B; do
   F="$A"; [ $V = B ] && F="$B"
   touch geocalib_amd/csrc/gclm_pass.hip geocalib_amd/csrc/gclm_api.hip
-  make -C geocalib_amd/csrc PASS_FLAGS="-fno-slp-vectorize $F" CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -Wall -Wno-unused-function $F" 2>&1 | grep -E "error|warning"
+  make -C geocalib_amd/csrc PASS_FLAGS="-fno-slp-vectorize $F" CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast-honor-pragmas -Wall -Wno-unused-function $F" 2>&1 | grep -E "error|warning"
   python scripts/dump_results.py gpurun_out/bits_$V.npz $MODELS
 done
 touch geocalib_amd/csrc/gclm_pass.hip geocalib_amd/csrc/gclm_api.hip

@@ -26,7 +26,7 @@ echo "=== A/B log-focal final sweep (ISO_FINAL)"
 for rep in 1 2; do
   for F in "-DGCLM_ISO_FINAL=0" ""; do
     touch geocalib_amd/csrc/gclm_api.hip
-    make -C geocalib_amd/csrc CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -Wall -Wno-unused-function $F" 2>&1 | grep -E "error|warning"
+    make -C geocalib_amd/csrc CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast-honor-pragmas -Wall -Wno-unused-function $F" 2>&1 | grep -E "error|warning"
     echo "== [$F] rep $rep"; python scripts/sweep_probe.py pinhole,simple_radial,radial 1024 2>&1 | grep -v amdgpu.ids
   done
 done | tee gpurun_out/r03/ab_iso_final.log
