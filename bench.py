@@ -286,7 +286,7 @@ def main():
                                else "all_reduce(sum) of per-group Schur partials"),
                 "collectives_per_step": 1 if gs == 0 or args.shared_by_group else args.lm_steps,
                 "collective_bytes": (n_total * 4 * (8 + 3 + _lib.INFO_STRIDE) if gs == 0 or args.shared_by_group
-                                     else (n_total // gs) * 4 * _lib.SHARED_PARTIAL_STRIDE),
+                                     else n_groups * 4 * _lib.SHARED_PARTIAL_STRIDE),
                 "collective_ms": round(coll_ms_max, 4), "backend": args.backend,
                 "comm": ("gclm_comm_* (RCCL behind the C ABI, on the solve's stream)" if comm is not None
                          else "torch.distributed"),
