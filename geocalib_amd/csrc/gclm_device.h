@@ -297,7 +297,8 @@ __device__ inline void reduce_image_partials(const float* image_partials, int nc
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
                 const int c = c0 + j * stride;
-                v[j] = c < nchunks ? p[(size_t)c * nacc] : 0.f;
+                const float t = p[(size_t)min(c, nchunks - 1) * nacc];      // unconditional load (a clamped index), then
+                v[j] = c < nchunks ? t : 0.f;                                // a select: all loads of the batch in flight
             }
 #pragma unroll
             for (int j = 0; j < 32; ++j) d += v[j];

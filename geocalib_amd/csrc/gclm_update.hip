@@ -39,7 +39,8 @@ __device__ inline bool coop_reduce_partials(const float* partials, int B, int nc
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int c = c0 + j * stride;
-                v[j] = c < nchunks ? p[(size_t)c * nacc] : 0.f;
+                const float t = p[(size_t)min(c, nchunks - 1) * nacc];      // unconditional load (a clamped index), then
+                v[j] = c < nchunks ? t : 0.f;                                // a select: all loads of the batch in flight
             }
 #pragma unroll
             for (int j = 0; j < 16; ++j) d += v[j];
@@ -413,7 +414,10 @@ __global__ __launch_bounds__(kGroups * kSlots) void shared_step_kernel(SolveCtx 
                 for (int q0 = 0; q0 < c.nchunks; q0 += 16) {          // 16 loads in flight, ascending order (see above)
                     float v[16];
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) v[j] = q0 + j < c.nchunks ? p[(size_t)(q0 + j) * nacc] : 0.f;
+                    for (int j = 0; j < 16; ++j) {
+                        const float t = p[(size_t)min(q0 + j, c.nchunks - 1) * nacc];      // unconditional (clamped), then a select
+                        v[j] = q0 + j < c.nchunks ? t : 0.f;
+                    }
 #pragma unroll
                     for (int j = 0; j < 16; ++j) d += v[j];
                 }

@@ -326,10 +326,16 @@ def test_hip_matches_oracle_shared16_eight_groups(dev, oracle, model):
     data, parts = _shared16(model, groups)
     conf = {"camera_model": model, "shared_intrinsics": True, "num_steps": 20, "early_stop": False}
     out = run({**conf, "group_size": 16}, data, dev)
+    from conftest import measure_result
     for i, (d, cams, _) in enumerate(parts):
         ref = oracle.solve(d, conf, precision="f32")
         sub = {k: v[16 * i:16 * (i + 1)] for k, v in out.items()}
-        compare_result(sub, ref, TOL, f"shared16x8/{model}/g{groups[i]}")
+        # the roll uncertainty of a frame that looks almost straight up or down is ill-conditioned (Gravity.J_rp at
+        # |g_z| -> 1, gravity.py:69-101): the oracle's own float32 and float64 builds differ by 1e-4 there, so the
+        # uncertainties get 10 x that on top of their gate
+        own = measure_result(ref, oracle.solve(d, conf, precision="f64"))
+        compare_result(sub, ref, {**TOL, "unc": TOL["unc"] + 10 * own["unc"], "cov": TOL["cov"] + 10 * own["cov"]},
+                       f"shared16x8/{model}/g{groups[i]}")
         assert np.abs(sub["camera"][0, 3] / cams[0, 3] - 1) < 1e-2                    # and it is the ground truth
 
 
@@ -698,7 +704,7 @@ FUZZ_UNDETERMINED_2024 = {"pinhole": 1, "simple_radial": 1, "radial": 2, "simple
 
 def yardstick_instability(oracle, data, conf):
     """Second opinion on a draw that missed its gate: does the oracle's own float32 evaluation hold up along the WAY?
-    Returns a reason (str) or None.  Two diagnoses, both of the reference ALGORITHM in float32, not of the HIP path:
+    Returns a reason (str) or None.  Three diagnoses, all of the reference ALGORITHM in float32, not of the HIP path:
       * its float32 and float64 trajectories part by more than 1e-3 at some step (the k-column of simple_divisional
         cancels for small |k|, camera.py:913: fuzz 19/198 -- at step 2 float32 and float64 differ by 6 % in the focal and
         0.1 in k; where an implementation lands there decides whether it then stalls for 20 steps, DESIGN section 5);
@@ -722,6 +728,15 @@ def yardstick_instability(oracle, data, conf):
         drift = ((t32["final_cost"] - cost.min(0)) / np.maximum(cost.min(0), floor)).max()
         if drift > 1e-3:
             return f"the oracle's final cost sits {drift:.1e} above its own minimum (post-convergence drift)"
+        if n >= 2 and t32["stop_at"][0] < n:
+            # its cost has converged (the allclose test passed at stop_at) and yet its iterates keep moving: a limit
+            # cycle (fuzz 20/136: radial on a latitude-only draw, k2 pinned at its 0.7 clamp (camera.py:700), k1 alternating
+            # between -0.2417 and -0.2440 from step to step) -- which phase an implementation ends in is one step's luck
+            last = max(np.abs(a["cam"][n - 1, :, :2] / a["cam"][n - 2, :, :2] - 1).max(),
+                       np.abs(a["cam"][n - 1, :, 2:] - a["cam"][n - 2, :, 2:]).max(),
+                       np.abs(a["gravity"][n - 1] - a["gravity"][n - 2]).max())
+            if last > 1e-4:
+                return f"the oracle's iterates still move by {last:.1e} per step at a converged cost (limit cycle)"
     return None
 
 
