@@ -51,7 +51,7 @@ def main():
             table[m][kind]["cases"] = counts[(m, kind)]
     systems = {k: v for k, v in rec.items() if k.startswith("system/")}
     fuzz = collections.defaultdict(lambda: {"draws": 0, "undetermined": 0, "gated": 0, "by_yardstick": collections.Counter(),
-                                            "worst": [0, 0, 0, 0], "worst_over_gate": 0.0})
+                                            "worst": [0, 0, 0, 0], "worst_over_gate": 0.0, "beyond_gate_on_unstable_yardstick": []})
     for label, v in rec.items():
         if not label.startswith("fuzz/"):
             continue
@@ -59,6 +59,9 @@ def main():
         f["draws"] += 1
         if v.get("undetermined"):
             f["undetermined"] += 1
+            continue
+        if v.get("excused"):             # beyond its gate, and the oracle's own float32 evaluation shown unstable on the draw
+            f["beyond_gate_on_unstable_yardstick"].append({"case": label, "spread": v["spread"], "gate": v["tol"], "diagnosis": v["excused"]})
             continue
         f["gated"] += 1
         f["by_yardstick"][v["yardstick"]] += 1
@@ -78,7 +81,8 @@ def main():
                     f"{q} {row[q]['worst']:.1e}" for q in QUANT if q in row))
     for seed, ms in fz.items():
         tot = {k: sum(v[k] for v in ms.values()) for k in ("draws", "undetermined", "gated")}
-        print(f"fuzz seed {seed}: {tot}  worst/gate {max(v['worst_over_gate'] for v in ms.values()):.2f}")
+        exc = [e["case"] for v in ms.values() for e in v["beyond_gate_on_unstable_yardstick"]]
+        print(f"fuzz seed {seed}: {tot}  worst/gate {max(v['worst_over_gate'] for v in ms.values()):.2f}  beyond the gate on an unstable yardstick: {exc}")
     if out_json:
         with open(out_json, "w") as fh:
             json.dump(out, fh, indent=1)
