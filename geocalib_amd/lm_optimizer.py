@@ -191,6 +191,7 @@ class LMOptimizer(nn.Module):
         self.setup_optimization_and_priors(shared_intrinsics=conf.shared_intrinsics)
         self._handles: Dict[Tuple[int, int], _Handle] = {}
         self._warned_training = False
+        self._warned_chunked_stop = False
 
     # ------------------------------------------------------------------ reference API
     def set_camera_model(self, camera_model: str) -> None:
@@ -342,9 +343,17 @@ class LMOptimizer(nn.Module):
 
     def _calibrate_chunked(self, data: Dict[str, torch.Tensor], B: int):
         """Batches beyond 65 535 images: independent images are solved in slices of one C call each.  The device
-        early stop is per call, as it is per shard in parallel.calibrate_sharded."""
+        early stop is per call -- per slice -- which is said once in a warning (parallel.calibrate_sharded, where the
+        same would make results depend on the world size, refuses early_stop instead)."""
         if self.shared_intrinsics:
             raise ValueError(f"a shared-intrinsics batch is limited to {self._MAX_CALL} frames per call")
+        if self.conf.early_stop and not self._warned_chunked_stop:
+            # the reference's stop is ONE decision over the whole batch (lm_optimizer.py:90-92, 619-625); here every slice
+            # of 65 535 images takes its own, so `stop_at` (and the step a slice's images stop at) can differ per slice
+            self._warned_chunked_stop = True
+            logger.warning("geocalib_amd.LMOptimizer: a batch of %d images is solved in slices of %d; with early_stop=True "
+                           "the batch-global stop is evaluated per slice (pass early_stop=False for slice-independent "
+                           "results)", B, self._MAX_CALL)
         per_image = ("up_field", "latitude_field", "up_confidence", "latitude_confidence", "prior_focal",
                      "prior_gravity", "prior_dist")
         cams, gravs, infos, raws = [], [], [], []
