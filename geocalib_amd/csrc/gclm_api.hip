@@ -2,6 +2,8 @@
 //
 // A solve is 2*num_steps+4 asynchronous launches on the caller's stream and no host round trip (nor memset):
 //   init | { sweep(theta_i) ; update_i } x num_steps | prep_final ; sweep(theta_final, rpf) ; finalize
+// and num_steps+3 for a single image (one launch per LM step, use_fused):
+//   init | fused(step) x num_steps | fused(final) | finalize
 // (the reference syncs twice per step: H,G -> CPU Cholesky -> device, and torch.allclose).
 #include <cstdarg>
 #include <cstdio>

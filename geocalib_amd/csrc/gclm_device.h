@@ -1,5 +1,5 @@
-// gclm_device.h -- per-image device logic shared by the update kernels (gclm_update.hip) and the fused
-// "last workgroup of an image applies the LM step" tail of the sweep (gclm_pass.hip).  gfx950 only.
+// gclm_device.h -- per-image device logic shared by the update kernels (gclm_update.hip) and the prologue of the
+// one-launch-per-step sweep for single images (gclm_pass.hip: fused_step_kernel).  gfx950 only.
 #pragma once
 #include "gclm_internal.h"
 

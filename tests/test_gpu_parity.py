@@ -958,7 +958,8 @@ def test_c_abi_from_plain_c(dev, tmp_path):
         assert np.allclose(got[:, 3:6], out["gravity"], atol=2e-5)
 
 
-@pytest.mark.parametrize("extra", [[], ["--shared-group", "16"], ["--shared-group", "16", "--shared-by-group"]])
+@pytest.mark.parametrize("extra", [[], ["--shared-group", "16"], ["--shared-group", "16", "--shared-by-group"],
+                                   ["--shared-group", "16", "--virtual-world", "8"]])
 def test_bench_multi_rank_path_on_one_gpu(dev, extra):
     """bench.py's N>1 code path (image sharding + ONE gather; shared-intrinsics frame split + ONE all-reduce per
     step) with two real processes that share this GPU and talk over gloo: the JSON line must describe the
@@ -982,7 +983,13 @@ def test_bench_multi_rank_path_on_one_gpu(dev, extra):
     # the N>1 line is attributable: ranks seen by the communicator, every rank's own step time, time in the collective
     mg = out["multi_gpu"]
     assert mg["ranks_seen"] == 2 and len(mg["per_rank_ms"]) == 2 and all(t > 0 for t in mg["per_rank_ms"])
-    assert mg["collective_ms"] >= 0 and mg["collectives_per_step"] == (20 if extra == ["--shared-group", "16"] else 1)
+    split = "--shared-group" in extra and "--shared-by-group" not in extra
+    assert mg["collective_ms"] >= 0 and mg["collectives_per_step"] == (20 if split else 1)
+    if "--virtual-world" in extra:      # two real ranks with the per-rank shape of an 8-GPU run: 2 frames of each of 32 groups
+        assert mg["virtual_world"] == 8 and mg["collective_bytes"] == 32 * 32 * 4
+        assert "per-rank shape of a 8-GPU run" in out["config"]["workload"]
+    elif split:
+        assert mg["collective_bytes"] == 8 * 32 * 4                      # 128 frames = 8 groups of 16, split over the 2 ranks
     assert len(out["ms_per_step_repeats"]) == out["repeats"] == 3
 
 
