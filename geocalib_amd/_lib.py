@@ -89,6 +89,8 @@ _SIGNATURES = {
     "gclm_comm_last_error": (C.c_char_p, [_P]),
     "gclm_comm_all_gather": (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
     "gclm_comm_all_reduce_sum": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "gclm_comm_all_reduce_sum_i32": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "gclm_set_stop_comm": (C.c_int, [_P, _P]),
     "gclm_set_sweep_iters": (C.c_int, [_P, C.c_int]),
     "gclm_set_fused_steps": (C.c_int, [_P, C.c_int]),
     "gclm_set_timing": (C.c_int, [_P, C.c_int]),

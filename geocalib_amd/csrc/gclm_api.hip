@@ -44,6 +44,7 @@ struct gclm_handle {
     } sh;
     int sweep_iters = 0;            // gclm_set_sweep_iters: 0 = built-in choice
     int fused_mode = -1;            // gclm_set_fused_steps: -1 = built-in choice, 0 = never, 1 = whenever it is valid
+    gclm_comm* stop_comm = nullptr; // gclm_set_stop_comm: the batch-global early stop spans the ranks of this communicator
     // optional timing of the sweep launches
     bool timing = false;
     std::vector<hipEvent_t> ev;
@@ -190,7 +191,8 @@ int timed_sweep(gclm_handle* h, const SweepArgs& a, hipStream_t s, const FusedAr
 // workgroup (one image) or off, for independent intrinsics on the float4 path.
 bool use_fused(const gclm_handle* h, int B, const Geometry& g) {
     const gclm_config& c = h->cfg;
-    const bool valid = !c.shared_intrinsics && g.vec == 4 && (B == 1 || !c.early_stop) && B > 0;
+    const bool valid = !c.shared_intrinsics && g.vec == 4 && (B == 1 || !c.early_stop) && B > 0 &&
+                       !(c.early_stop && h->stop_comm);       // a stop that spans ranks is never local to a workgroup
     if (!valid || h->fused_mode == 0) return false;
     if (h->fused_mode == 1) return true;
     return (long long)B * g.nchunks <= GCLM_FUSED_MAX_WORKGROUPS;
@@ -343,6 +345,12 @@ int gclm_set_sweep_iters(gclm_handle* h, int iters) {
     return 0;
 }
 
+int gclm_set_stop_comm(gclm_handle* h, gclm_comm* c) {
+    if (!h) return -1;
+    h->stop_comm = c;
+    return 0;
+}
+
 int gclm_set_fused_steps(gclm_handle* h, int mode) {
     if (!h) return -1;
     if (mode < -1 || mode > 1) return fail(h, -3, "gclm_set_fused_steps: mode %d not in {-1, 0, 1}", mode);
@@ -423,6 +431,11 @@ static int run_solve(gclm_handle* h, const float* d_up, const float* d_lat, cons
         } else {
             GCLM_HIP(h, launch_shared_step(c, step, s));     // reduce + Schur solve + update: one launch
         }
+        // a batch sharded over ranks: "whose cost still moved" is a count over ALL ranks' images (every step, also after
+        // the stop -- the counters of skipped steps stay 0 everywhere -- so that the ranks' collectives keep matching)
+        if (es && h->stop_comm && step >= 1)
+            if (gclm_comm_all_reduce_sum_i32(h->stop_comm, &c.ctrl->notclose[step], 1, s) != 0)
+                return fail(h, -20, "early-stop all-reduce failed: %s", gclm_comm_last_error(h->stop_comm));
     }
     GCLM_HIP(h, launch_prep_final(c, s));
     const SweepArgs a = sweep_args(h, d_up, d_lat, d_up_conf, d_lat_conf, c.pb_final, geo, false, 0);

@@ -79,4 +79,10 @@ int gclm_comm_all_reduce_sum(gclm_comm* c, float* d_buf, size_t count, void* str
     return r == ncclSuccess ? 0 : cfail(c, -20, "ncclAllReduce", ncclGetErrorString(r));
 }
 
+int gclm_comm_all_reduce_sum_i32(gclm_comm* c, int32_t* d_buf, size_t count, void* stream) {
+    if (!c || !d_buf) return cfail(c, -1, "gclm_comm_all_reduce_sum_i32", "null argument");
+    ncclResult_t r = ncclAllReduce(d_buf, d_buf, count, ncclInt32, ncclSum, c->comm, static_cast<hipStream_t>(stream));
+    return r == ncclSuccess ? 0 : cfail(c, -20, "ncclAllReduce", ncclGetErrorString(r));
+}
+
 }  // extern "C"

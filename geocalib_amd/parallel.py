@@ -232,12 +232,31 @@ def calibrate_sharded(opt: LMOptimizer, local_data: Dict[str, torch.Tensor], n_t
             raise ValueError(f"{n_total // gs} groups do not divide over {world_} ranks: give every rank the same number "
                              "of whole groups (or use SharedIntrinsicsSplit)")
     forced = os.environ.get("GCLM_FORCE_COLLECTIVES") == "1"
-    if opt.conf.early_stop and (comm is not None and (comm.nranks > 1 or forced) or collectives_on(group)):
-        # the reference's early stop is ONE decision over the whole batch (lm_optimizer.py:90-92, 619); each rank
-        # would take it over its own shard and the gathered result would depend on the world size
-        raise ValueError("calibrate_sharded needs early_stop=False (a fixed number of steps): the batch-global early "
-                         "stop is not shard-invariant")
-    out = opt(local_data)
+    multi = comm is not None and (comm.nranks > 1 or forced) or collectives_on(group)
+    stop_handle = None
+    if opt.conf.early_stop and multi:
+        # The reference's early stop is ONE decision over the whole batch (lm_optimizer.py:90-92, 619); every rank taking
+        # it over its own shard would make the gathered result depend on the world size.  With an
+        # RCCL communicator the per-step "cost still moved" counters are summed over the ranks on the solve's stream
+        # (gclm_set_stop_comm: one 4-byte all-reduce per LM step), so the stop IS the whole batch's.  Without one (gloo
+        # test rigs) only a fixed number of steps is shard-invariant.
+        stop_comm = comm
+        if stop_comm is None and dist.get_backend(group) == "nccl" and next(iter(local_data.values())).is_cuda:
+            stop_comm = getattr(opt, "_stop_comm", None)          # made once per optimiser (the results still travel by torch)
+            if stop_comm is None:
+                dev_index = next(iter(local_data.values())).device.index
+                stop_comm = opt._stop_comm = RcclComm.from_torch_group(
+                    dev_index if dev_index is not None else torch.cuda.current_device(), group)
+        if stop_comm is None:
+            raise ValueError("calibrate_sharded needs early_stop=False (a fixed number of steps) here: the batch-global early "
+                             "stop is only shard-invariant with an RCCL communicator (`comm`, or the nccl backend)")
+        stop_handle = opt._handle(next(iter(local_data.values())).device)
+        _lib.check(_lib.load().gclm_set_stop_comm(stop_handle.ptr, stop_comm._ptr), stop_handle.ptr, "gclm_set_stop_comm")
+    try:
+        out = opt(local_data)
+    finally:
+        if stop_handle is not None:
+            _lib.load().gclm_set_stop_comm(stop_handle.ptr, None)
     rows = pack_rows(*opt._last_raw)
     if comm is not None and (comm.nranks > 1 or forced):       # direct RCCL route (gclm_comm_all_gather; equal shards)
         assert n_total % comm.nranks == 0, "the direct RCCL route expects equal shards"

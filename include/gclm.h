@@ -33,7 +33,7 @@ extern "C" {
 
 /* ABI version: bumped whenever struct gclm_config or the export list changes (100 = round 1/2, 300 = round 3:
  * struct_size / abi_version / device moved into gclm_config, gclm_create lost its third argument, new entry points
- * gclm_set_sweep_iters, gclm_set_fused_steps, gclm_abi_config_size).  gclm_create refuses a gclm_config whose first two fields do not
+ * gclm_set_sweep_iters, gclm_set_fused_steps, gclm_set_stop_comm, gclm_comm_all_reduce_sum_i32, gclm_abi_config_size).  gclm_create refuses a gclm_config whose first two fields do not
  * carry the library's own sizeof(gclm_config) and GCLM_VERSION, with a message naming both sides. */
 #define GCLM_VERSION 300
 
@@ -287,6 +287,17 @@ int gclm_comm_destroy(gclm_comm* c);
 const char* gclm_comm_last_error(const gclm_comm* c);
 int gclm_comm_all_gather(gclm_comm* c, const float* d_send, float* d_recv, size_t count_per_rank, void* stream);
 int gclm_comm_all_reduce_sum(gclm_comm* c, float* d_buf, size_t count, void* stream);
+int gclm_comm_all_reduce_sum_i32(gclm_comm* c, int32_t* d_buf, size_t count, void* stream);
+
+/*
+ * The reference's early stop is ONE decision over the whole batch (lm_optimizer.py:90-92, 619-625).  For a batch
+ * sharded over the ranks of `c` (image sharding, configs[2]) that decision needs every rank's images: with a stop
+ * communicator set, gclm_solve / gclm_calibrate sum the per-step counter of images whose cost still moved over the
+ * ranks after every update (ONE 4-byte all-reduce per LM step, enqueued on the solve's stream, no host round trip), so
+ * every rank stops at the step the single-process solve of the whole batch would stop at, and reports that `stop_at`.
+ * Every rank must run the same num_steps.  NULL unsets it.  Without it a sharded solve must run with early_stop = 0.
+ */
+int gclm_set_stop_comm(gclm_handle* h, gclm_comm* c);
 
 /* Tuning / test hook (no reference counterpart): loop iterations per workgroup of the sweep (how an image is cut
  * into partial records; only the summation order depends on it).  0 restores the built-in choice (20, fewer for

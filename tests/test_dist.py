@@ -68,12 +68,14 @@ def test_gather_plan_reuses_its_buffers_world2():
 
 
 def _early_stop_worker(rank, world):
-    """calibrate_sharded refuses the batch-global early stop (not shard-invariant) before touching any tensor."""
+    """Without an RCCL communicator (gloo rigs, CPU tensors) calibrate_sharded refuses the batch-global early stop -- it
+    is only shard-invariant when the per-step counters can be summed over the ranks (gclm_set_stop_comm) -- before
+    touching any tensor."""
     import pytest
     from geocalib_amd import LMOptimizer
     from geocalib_amd.parallel import calibrate_sharded
     with pytest.raises(ValueError, match="early_stop=False"):
-        calibrate_sharded(LMOptimizer({"camera_model": "pinhole"}), {}, 8)
+        calibrate_sharded(LMOptimizer({"camera_model": "pinhole"}), {"latitude_field": torch.zeros(4, 1, 8, 8)}, 8)
 
 
 def test_calibrate_sharded_refuses_early_stop_world2():

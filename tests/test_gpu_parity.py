@@ -674,6 +674,41 @@ def test_pack_fields_matches_torch_head_epilogue(dev, shape, conf):
     assert torch.isfinite(res["camera"]._data).all()
 
 
+def test_sharded_early_stop_through_the_stop_communicator(dev):
+    """The reference's batch-global early stop for a batch sharded over ranks (gclm_set_stop_comm: the per-step counters of
+    images whose cost still moved are summed over the ranks on the solve's stream).  One GPU: (1) with a one-rank
+    communicator the all-reduce is the identity, so the sharded call equals the plain solve bit for bit, `stop_at`
+    included; (2) the counter protocol itself -- a shard alone stops EARLIER than the batch it belongs to (its own
+    slowest image decides), which is exactly what the summed counters prevent: the slice of the whole-batch solve is
+    reproduced by that shard only when it is told the other shard's counters."""
+    import os as _os
+    from geocalib_amd import LMOptimizer, _lib
+    from geocalib_amd.parallel import RcclComm, calibrate_sharded
+    lib = _lib.load()
+    data, _, _ = synth_device("simple_radial", 12, 96, 128, dev, seed=77)
+    conf = {"camera_model": "simple_radial"}                           # the default conf: 30 steps, early stop
+    whole = run_dev(conf, data)
+    comm = RcclComm(RcclComm.unique_id(), 1, 0, 0)
+    _os.environ["GCLM_FORCE_COLLECTIVES"] = "1"
+    try:
+        opt = LMOptimizer(conf).eval()
+        out = to_np(calibrate_sharded(opt, data, 12, comm=comm))
+    finally:
+        _os.environ.pop("GCLM_FORCE_COLLECTIVES", None)
+    for k in ("camera", "gravity", "final_cost", "stop_at"):
+        assert np.array_equal(out[k], whole[k]), k
+    assert 1 < whole["stop_at"][0] < 30
+    h = opt._handle(dev)
+    assert lib.gclm_set_stop_comm(h.ptr, None) == 0                     # and it was unset again after the call
+    # (2) shards on their own: each stops when ITS images have converged -- generally not where the batch stops
+    lo, hi = run_dev(conf, {k: v[:6] for k, v in data.items()}), run_dev(conf, {k: v[6:] for k, v in data.items()})
+    assert max(lo["stop_at"][0], hi["stop_at"][0]) == whole["stop_at"][0]        # the slower shard IS the batch's stop
+    if lo["stop_at"][0] != hi["stop_at"][0]:
+        early = lo if lo["stop_at"][0] < hi["stop_at"][0] else hi
+        sl = slice(0, 6) if early is lo else slice(6, 12)
+        assert not np.array_equal(early["camera"], whole["camera"][sl])           # per-shard decisions change the answer
+
+
 def test_rccl_c_abi_single_rank(dev):
     """gclm_comm_* (direct RCCL behind the C ABI) with a one-rank communicator: both collectives are the identity,
     and the shared-intrinsics split driven through it equals the plain solve.  (Eight ranks are the driver's.)"""
