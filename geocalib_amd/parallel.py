@@ -23,7 +23,7 @@ import torch.distributed as dist
 from . import _lib
 from .camera import BaseCamera
 from .gravity import Gravity
-from .lm_optimizer import LMOptimizer, _dev_f32, get_trivial_estimation
+from .lm_optimizer import LMOptimizer, _dev_f32, _unit_gravity, get_trivial_estimation
 
 ROW = 8 + 3 + _lib.INFO_STRIDE   # packed floats per image
 
@@ -204,7 +204,8 @@ class RcclComm:
 
 def infos_from_rows(opt: LMOptimizer, rows: torch.Tensor, has_up: bool) -> Dict[str, torch.Tensor]:
     cam, grav, info = unpack_rows(rows)
-    out = {"camera": opt.camera_model(cam.contiguous()), "gravity": Gravity(grav.contiguous())}
+    # the rows hold the solve's own unit vectors: wrapped as they are (re-normalising would move their last bit)
+    out = {"camera": opt.camera_model(cam.contiguous()), "gravity": _unit_gravity(grav.contiguous())}
     out.update(opt._unpack_info(info, has_up))
     return out
 
