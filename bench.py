@@ -73,19 +73,20 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(args, n_images):
-    """Oracle (C port of the reference algorithm, OpenMP over images) on a bounded sample."""
-    from oracle import lm_oracle, synth
+def cpu_baseline(args, n_images, device_data):
+    """Oracle (C port of the reference algorithm, OpenMP over images) on a bounded sample: the FIRST n images of the very
+    batch the GPU was timed on, copied to the host (the checker runs after the timed region, on rank 0 at N = 1 only)."""
+    from oracle import lm_oracle
     cores = lm_oracle.effective_cpus()        # what the cgroup grants, not what the box has
     lm_oracle.build()
-    data, _, _ = synth.make_fields(args.seed, range(n_images), args.camera_model, args.height, args.width)
+    data = {k: v[:n_images].cpu().numpy() for k, v in device_data.items()}
     conf = {"camera_model": args.camera_model, "num_steps": args.lm_steps, "early_stop": False}
     t0 = time.perf_counter()
     lm_oracle.solve(data, conf, precision="f32", num_threads=cores)
     dt = time.perf_counter() - t0
     out = {"value": round(n_images / dt, 3), "unit": "images/sec", "cores": min(cores, n_images), "kind": "port",
-           "sample": f"{n_images} images {args.width}x{args.height}, {args.lm_steps} LM iters, oracle/lm_oracle.c "
-                     f"(float32, OpenMP over images), {dt:.1f} s"}
+           "sample": f"the first {n_images} images of the timed batch ({args.width}x{args.height}), {args.lm_steps} LM iters, "
+                     f"oracle/lm_oracle.c (float32, OpenMP over images), {dt:.1f} s"}
     ref = reference_torch(args)
     if ref is not None:
         out["reference_torch"] = ref
@@ -309,11 +310,11 @@ def main():
                 "algorithmic_bytes_per_launch": algo_bytes_per_launch, "avg_launch_ms": round(avg_ms, 4),
                 "launches_timed": sweep_n,
                 "whole_job_frac": round(value / world * (args.lm_steps + 1) * H * W * PLANES * 4 / 1e9 / HBM_PEAK_GBS, 4)}
-        if world == 1 and args.cpu_sample != 0:
+        if world == 1 and args.cpu_sample != 0 and gs == 0:      # (the port times independent solves: configs[1] / [3])
             from oracle.lm_oracle import effective_cpus
-            n = args.cpu_sample if args.cpu_sample > 0 else max(8, min(64, 2 * effective_cpus()))
+            n = min(B, args.cpu_sample if args.cpu_sample > 0 else max(8, 16 * effective_cpus()))   # ~7-10 s of CPU work
             try:
-                result["cpu_baseline"] = cpu_baseline(args, n)
+                result["cpu_baseline"] = cpu_baseline(args, n, data)
             except Exception as e:  # the checker must never take the product measurement down
                 result["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(result), flush=True)
