@@ -385,9 +385,24 @@ static int run_solve(gclm_handle* h, const float* d_up, const float* d_lat, cons
                      const float* d_lat_conf, int B, int H, int W, const InitArgs& ia, float* d_cam_out,
                      float* d_grav_out, float* d_info_out, void* stream) {
     if (int rc = check_shapes(h, d_lat, B, H, W)) return rc;
-    if (!d_cam_out || !d_grav_out || !d_info_out) return fail(h, -3, "null output pointer");
-    if (B == 0) return 0;
+    if (B > 0 && (!d_cam_out || !d_grav_out || !d_info_out)) return fail(h, -3, "null output pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (B == 0) {
+        // an empty shard still owes its peers the per-step collectives of a rank-spanning early stop (zero counters)
+        if (h->cfg.early_stop && h->stop_comm && h->cfg.num_steps > 1) {
+            DeviceGuard guard0(h->device);
+            GCLM_HIP(h, guard0.status);
+            SolveCtx& c0 = h->ctx;
+            c0.cfg = h->cfg;
+            c0.B = 0; c0.H = H; c0.W = W; c0.nchunks = 1; c0.n_groups = 0; c0.group_size = 1; c0.group_of_frame = nullptr;
+            if (int rc = ensure_workspace(h, 1, 1, 0)) return rc;
+            GCLM_HIP(h, launch_init(c0, ia, s));                               // thread 0 resets the counters
+            for (int step = 1; step < h->cfg.num_steps; ++step)
+                if (gclm_comm_all_reduce_sum_i32(h->stop_comm, &c0.ctrl->notclose[step], 1, s) != 0)
+                    return fail(h, -20, "early-stop all-reduce failed: %s", gclm_comm_last_error(h->stop_comm));
+        }
+        return 0;
+    }
     DeviceGuard guard(h->device);
     GCLM_HIP(h, guard.status);
     const bool al = is_aligned16(d_up) && is_aligned16(d_lat) && is_aligned16(d_up_conf) && is_aligned16(d_lat_conf);
