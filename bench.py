@@ -139,7 +139,7 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
-    local_dev = local_rank % torch.cuda.device_count() if args.backend == "gloo" else local_rank
+    local_dev = local_rank % torch.cuda.device_count()      # one rank per GPU; test rigs with fewer GPUs than ranks share them
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     # GCLM_FORCE_COLLECTIVES=1 under torchrun with ONE rank: every collective of the N>1 path runs (through RCCL)
