@@ -282,6 +282,17 @@ def test_reference_error_behaviour(dev):
     assert lib.gclm_solve(h.ptr, None, lat.data_ptr(), None, None, 0, 16, 16, buf.data_ptr(), buf.data_ptr(),
                           buf.data_ptr(), None) == 0    # empty batch is a no-op
     assert lib.gclm_workspace_bytes(h.ptr) >= 0
+    # the tuning hooks validate their argument and say what was wrong
+    assert lib.gclm_set_fused_steps(h.ptr, 5) == -3 and "gclm_set_fused_steps" in _lib.last_error(h.ptr)
+    assert lib.gclm_set_sweep_iters(h.ptr, -1) == -3 and "gclm_set_sweep_iters" in _lib.last_error(h.ptr)
+    assert lib.gclm_set_fused_steps(h.ptr, -1) == 0 and lib.gclm_set_sweep_iters(h.ptr, 0) == 0 and lib.gclm_set_stop_comm(h.ptr, None) == 0
+    # a handle cannot change its device, and a config of another ABI generation is refused by gclm_configure as well
+    cfg = opt._config(0)
+    cfg.device = 1
+    assert lib.gclm_configure(h.ptr, C.byref(cfg)) == -2 and "cannot move" in _lib.last_error(h.ptr)
+    cfg = opt._config(0)
+    cfg.abi_version = 100
+    assert lib.gclm_configure(h.ptr, C.byref(cfg)) == -5 and "ABI mismatch" in _lib.last_error(h.ptr)
 
 
 # ------------------------------------------------------------------ shared intrinsics extensions
