@@ -45,3 +45,18 @@ mix = dict(sets[slow]); mix["up_field"] = sets[fast]["up_field"]
 print(f"  slow set with the FAST set's up_field: {sweep_us(opt, mix):7.1f} us")
 mix = dict(sets[fast]); mix["up_field"] = sets[slow]["up_field"]
 print(f"  fast set with the SLOW set's up_field: {sweep_us(opt, mix):7.1f} us")
+
+
+# Is it THIS access pattern, or the region?  A plain read of every tensor (torch's sum kernel), per set.
+def read_gbs(t, n=5):
+    t.sum(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        t.sum()
+    e1.record(); torch.cuda.synchronize()
+    return t.numel() * 4 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+for i, d in enumerate(sets):
+    print(f"set {i}: plain read GB/s  " + "  ".join(f"{k[:6]} {read_gbs(v):6.0f}" for k, v in d.items()), flush=True)
