@@ -93,6 +93,7 @@ _SIGNATURES = {
     "gclm_set_stop_comm": (C.c_int, [_P, _P]),
     "gclm_set_sweep_iters": (C.c_int, [_P, C.c_int]),
     "gclm_set_fused_steps": (C.c_int, [_P, C.c_int]),
+    "gclm_set_paced_launches": (C.c_int, [_P, C.c_int]),
     "gclm_set_timing": (C.c_int, [_P, C.c_int]),
     "gclm_last_pass_timing": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
 }

@@ -5,6 +5,7 @@
 // and num_steps+3 for a single image (one launch per LM step, use_fused):
 //   init | fused(step) x num_steps | fused(final) | finalize
 // (the reference syncs twice per step: H,G -> CPU Cholesky -> device, and torch.allclose).
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -45,6 +46,10 @@ struct gclm_handle {
     int sweep_iters = 0;            // gclm_set_sweep_iters: 0 = built-in choice
     int fused_mode = -1;            // gclm_set_fused_steps: -1 = built-in choice, 0 = never, 1 = whenever it is valid
     gclm_comm* stop_comm = nullptr; // gclm_set_stop_comm: the batch-global early stop spans the ranks of this communicator
+    int paced_depth = 0;            // gclm_set_paced_launches: 0 = off, d = launch k waits for launch k-d's report
+    int* progress_host = nullptr;   // ... the host-mapped word the launches report to (owned), its device alias
+    int* progress_dev = nullptr;
+    int epoch = 0;                  // ... and the tag of the current solve in it
     // optional timing of the sweep launches
     bool timing = false;
     std::vector<hipEvent_t> ev;
@@ -329,6 +334,7 @@ int gclm_destroy(gclm_handle* h) {
     DeviceGuard guard(h->device);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     if (h->ws) (void)hipFree(h->ws);
+    if (h->progress_host) (void)hipHostFree(h->progress_host);
     delete h;
     return 0;
 }
@@ -355,6 +361,24 @@ int gclm_set_fused_steps(gclm_handle* h, int mode) {
     if (!h) return -1;
     if (mode < -1 || mode > 1) return fail(h, -3, "gclm_set_fused_steps: mode %d not in {-1, 0, 1}", mode);
     h->fused_mode = mode;
+    return 0;
+}
+
+int gclm_set_paced_launches(gclm_handle* h, int depth) {
+    if (!h) return -1;
+    if (depth < 0 || depth > 16) return fail(h, -3, "gclm_set_paced_launches: depth %d out of range [0, 16]", depth);
+    if (depth > 0 && !h->progress_host) {
+        DeviceGuard guard(h->device);
+        GCLM_HIP(h, guard.status);
+        void* p = nullptr;
+        GCLM_HIP(h, hipHostMalloc(&p, 64, hipHostMallocMapped));
+        h->progress_host = static_cast<int*>(p);
+        *h->progress_host = 0;
+        void* d = nullptr;
+        GCLM_HIP(h, hipHostGetDevicePointer(&d, p, 0));
+        h->progress_dev = static_cast<int*>(d);
+    }
+    h->paced_depth = depth;
     return 0;
 }
 
@@ -422,8 +446,31 @@ static int run_solve(gclm_handle* h, const float* d_up, const float* d_lat, cons
     if (use_fused(h, B, geo)) {
         // init | fused(step) x num_steps | fused(final) | finalize : num_steps + 3 launches, partial records double-buffered
         float* const part[2] = {c.partials, c.partials2};
+        // Paced launches (single image with early stop): the launches after the stop are skipped on the device, but each
+        // still costs its turn on the queue (2.3 us x 21 of a default-conf solve).  Launch k is therefore only issued
+        // once launch k - depth has reported (a word in host-mapped memory), and none once the stop is reported.  What
+        // the host sees only decides how many launches it issues: the device-side skip stays in force, so a late or
+        // missing report costs time, never correctness; the wait gives up after 20 ms.
+        const bool paced = h->paced_depth > 0 && es && B == 1 && h->progress_host;
+        if (paced) h->epoch = (h->epoch + 1) & kPacedEpochMask;
+        bool stop_seen = false, pace = paced;
+        auto reported = [&](int launch) {          // has `launch` (or a later one) of THIS solve reported?  sets stop_seen
+            const int v = __atomic_load_n(h->progress_host, __ATOMIC_ACQUIRE);
+            if (((v >> kPacedEpochShift) & kPacedEpochMask) != h->epoch) return false;
+            if (v & kPacedStopBit) stop_seen = true;
+            return stop_seen || (v & 0xffff) >= launch + 1;
+        };
         for (int step = 0; step <= h->cfg.num_steps; ++step) {
             const bool fin = step == h->cfg.num_steps;
+            if (pace && !fin && step >= h->paced_depth) {
+                const auto t0 = std::chrono::steady_clock::now();
+                for (unsigned spin = 0; !reported(step - h->paced_depth); ++spin)
+                    if ((spin & 0x3ff) == 0x3ff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+                        pace = false;              // the device is busy elsewhere: issue the rest unpaced
+                        break;
+                    }
+            }
+            if (stop_seen && !fin) continue;       // the final launch finds the stop in the counters, as it always does
             SweepArgs a = sweep_args(h, d_up, d_lat, d_up_conf, d_lat_conf, c.pb[0], geo, !fin, 0);
             a.partials = part[step & 1];
             FusedArgs f;
@@ -431,6 +478,8 @@ static int run_solve(gclm_handle* h, const float* d_up, const float* d_lat, cons
             f.step = step;
             f.is_final = fin ? 1 : 0;
             f.partials_in = part[(step + 1) & 1];
+            f.progress = (paced && !fin) ? h->progress_dev : nullptr;
+            f.epoch = h->epoch;
             if (int rc = timed_sweep(h, a, s, &f)) return rc;
         }
         SolveCtx cf = c;

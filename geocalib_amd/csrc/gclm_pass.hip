@@ -987,6 +987,11 @@ __global__ __launch_bounds__(kBlock) void fused_step_kernel(const SweepArgs a, c
         Ps = p;
         go = (f.is_final || !stop_now) ? 1 : 0;
         if (chunk == 0) {
+            // paced launches: tell the host how far image 0 has come and whether the stop fired, so that it stops issuing
+            // launches nobody needs (a system-scope store into host-mapped memory; nothing else is ordered by it)
+            if (f.progress && b == 0)
+                __hip_atomic_store(f.progress, (f.epoch << kPacedEpochShift) | (stop_now ? kPacedStopBit : 0) | (step + 1),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (commit) {
                 c.state[step & 1][b] = fin;
                 if (moved) atomicAdd(&c.ctrl->notclose[step - 1], 1);
@@ -1002,12 +1007,13 @@ __global__ __launch_bounds__(kBlock) void fused_step_kernel(const SweepArgs a, c
     if (!go) return;
     // workgroup-uniform parameter block: LDS -> SGPRs (the sweep addresses it as scalar operands)
     PBlock P;
-    {
-        const float* src = reinterpret_cast<const float*>(&Ps);
-        float* dst = reinterpret_cast<float*>(&P);
-#pragma unroll
-        for (int i = 0; i < kPBlockFloats; ++i)
-            dst[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, src[i])));
+    {   // field by field: addressed as a float array, a slice of P stayed an alloca in one instantiation
+        auto uni = [](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); };
+        P.ifx = uni(Ps.ifx); P.ify = uni(Ps.ify); P.cx = uni(Ps.cx); P.cy = uni(Ps.cy);
+        P.ga = uni(Ps.ga); P.gb = uni(Ps.gb); P.gc = uni(Ps.gc); P.k1 = uni(Ps.k1);
+        P.T00 = uni(Ps.T00); P.T01 = uni(Ps.T01); P.T10 = uni(Ps.T10); P.T11 = uni(Ps.T11);
+        P.T20 = uni(Ps.T20); P.T21 = uni(Ps.T21); P.wfx = uni(Ps.wfx); P.wfy = uni(Ps.wfy);
+        P.k2 = uni(Ps.k2); P.pad0 = P.pad1 = P.pad2 = 0.f;
     }
     sweep_body<MODEL, HAS_UP, HAS_UPC, HAS_LATC, LOGF, 4>(a, P, b, chunk);
 }

@@ -42,6 +42,9 @@ class GeoCalib(nn.Module):
         self.field_model = field_model
         self.preprocess = preprocess
         self.optimizer = LMOptimizer({**optimizer_options})
+        # calibrate() reads the camera on the host right after the solve (_post_process), so nothing is lost by letting a
+        # single-image solve pace its launches against the device's early stop (LMOptimizer.paced_launches)
+        self.optimizer.paced_launches = 3
 
     def _post_process(self, camera: BaseCamera, img_data: Dict[str, torch.Tensor], out: Dict[str, torch.Tensor]):
         """Undo scaling / cropping and bring the fields back to the input resolution."""

@@ -59,6 +59,12 @@ class _Handle:
         _lib.check(rc, None, "gclm_create")
         self.key = cfg.key()
         self.device = cfg.device
+        self.paced = 0
+
+    def set_paced(self, depth: int):
+        if depth != self.paced:
+            _lib.check(_lib.load().gclm_set_paced_launches(self.ptr, int(depth)), self.ptr, "gclm_set_paced_launches")
+            self.paced = depth
 
     def destroy(self):
         if self.ptr:
@@ -249,6 +255,12 @@ class LMOptimizer(nn.Module):
 
     _MAX_HANDLES = 16      # workspaces kept alive per optimiser (each is O(B) small records; LRU beyond this)
 
+    # Host-side knob without a reference counterpart (include/gclm.h: gclm_set_paced_launches).  d > 0: a single-image
+    # solve with early stop issues launch k only after launch k - d has reported, and none after the stop -- the call then
+    # blocks for about the LM loop's duration instead of returning at once, and finishes ~20 % earlier (no queue turns for
+    # the launches after the stop).  For callers that read the result right away; GeoCalib sets 3.  Results are unaffected.
+    paced_launches = 0
+
     def _handle(self, device: torch.device, stream: int = None) -> _Handle:
         """The gclm_handle of (device, stream): solves issued from different torch streams (e.g. the CNN of batch k+1
         overlapping the LM of batch k) get different workspaces; the same stream reuses its own, in order."""
@@ -268,6 +280,7 @@ class LMOptimizer(nn.Module):
         else:
             h.configure(cfg)
         self._handles[key] = h            # most recently used last
+        h.set_paced(int(self.paced_launches))
         return h
 
     @staticmethod

@@ -33,7 +33,7 @@ extern "C" {
 
 /* ABI version: bumped whenever struct gclm_config or the export list changes (100 = round 1/2, 300 = round 3:
  * struct_size / abi_version / device moved into gclm_config, gclm_create lost its third argument, new entry points
- * gclm_set_sweep_iters, gclm_set_fused_steps, gclm_set_stop_comm, gclm_comm_all_reduce_sum_i32, gclm_abi_config_size).  gclm_create refuses a gclm_config whose first two fields do not
+ * gclm_set_sweep_iters, gclm_set_fused_steps, gclm_set_paced_launches, gclm_set_stop_comm, gclm_comm_all_reduce_sum_i32, gclm_abi_config_size).  gclm_create refuses a gclm_config whose first two fields do not
  * carry the library's own sizeof(gclm_config) and GCLM_VERSION, with a message naming both sides. */
 #define GCLM_VERSION 300
 
@@ -311,6 +311,16 @@ int gclm_set_sweep_iters(gclm_handle* h, int iters);
  * intrinsics, 16-byte aligned fields of a width divisible by 4, and a single image or early_stop = 0 -- the
  * batch-global stop of lm_optimizer.py:619-625 is only decidable inside a launch when the batch is one image). */
 int gclm_set_fused_steps(gclm_handle* h, int mode);
+
+/* Single image with early_stop = 1 on the one-launch-per-step path: the launches after the stop return at their first
+ * instruction, but each still takes its turn on the queue (21 of the 33 launches of a default-conf solve that stops at
+ * step 9).  depth > 0 PACES the launches: launch k is issued once launch k - depth has reported to a word in
+ * host-mapped memory, and none after the stop has been reported -- gclm_solve / gclm_calibrate then BLOCK the calling
+ * thread for about the duration of the LM loop (the results are still produced asynchronously on the stream).  For
+ * callers that read the result right away (the reference's GeoCalib.calibrate does: extractor.py:51-69).  0 (default)
+ * = off: every launch is issued at once, the call returns immediately.  Ignored where it cannot help (more than one
+ * image, early_stop = 0, the two-launch path).  Results do not depend on it.  depth in [0, 16]; 3 is a good value. */
+int gclm_set_paced_launches(gclm_handle* h, int depth);
 
 /* Timing helper: when enabled, every sweep launch is bracketed by HIP events on the solve's stream;
  * gclm_last_pass_timing waits for the recorded launches, returns their count and summed duration

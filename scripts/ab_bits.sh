@@ -7,8 +7,9 @@ cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out
 for V in A B; do
   F="$A"; [ $V = B ] && F="$B"
+  BASE="${PASS_BASE_A:-}"; [ $V = B ] && BASE="${PASS_BASE_B:-}"        # optional: another PASS_BASE (Makefile) per side
   touch geocalib_amd/csrc/gclm_pass.hip geocalib_amd/csrc/gclm_api.hip
-  make -C geocalib_amd/csrc PASS_FLAGS="-fno-slp-vectorize $F" CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast-honor-pragmas -Wall -Wno-unused-function $F" 2>&1 | grep -E "error|warning"
+  make -C geocalib_amd/csrc ${BASE:+PASS_BASE="$BASE"} PASS_FLAGS="$F" CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast-honor-pragmas -Wall -Wno-unused-function $F" 2>&1 | grep -E "error|warning"
   python scripts/dump_results.py gpurun_out/bits_$V.npz $MODELS
 done
 touch geocalib_amd/csrc/gclm_pass.hip geocalib_amd/csrc/gclm_api.hip

@@ -21,5 +21,10 @@ for model in models:
             torch.cuda.synchronize()
             for k, v in out.items():
                 res[f"{model}/{B}x{H}x{W}/{steps}/{k}"] = (v._data if hasattr(v, "_data") else v).cpu().numpy()
+    data, _, _ = synth_fields(model, 1, 480, 640, dev, seed=78)          # one image, default conf: one launch per step, early stop
+    out = LMOptimizer({"camera_model": model}).eval()(data)
+    torch.cuda.synchronize()
+    for k, v in out.items():
+        res[f"{model}/single/default/{k}"] = (v._data if hasattr(v, "_data") else v).cpu().numpy()
 np.savez(out_path, **res)
 print(f"{out_path}: {len(res)} tensors")

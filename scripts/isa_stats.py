@@ -27,7 +27,7 @@ def main():
         i = args.index("--dump"); dump = args[i + 1]; del args[i:i + 2]
     models = [int(a) for a in args] or [0, 1, 2, 3]
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast-honor-pragmas",
-                    "-fno-slp-vectorize", *os.environ.get("EXTRA", "").split(), "-S", "--cuda-device-only", "-o", asm, src],
+                    "-fno-slp-vectorize", *os.environ.get("PASS_BASE_EXTRA", "-mllvm -disable-vector-combine").split(), *os.environ.get("EXTRA", "").split(), "-S", "--cuda-device-only", "-o", asm, src],
                    check=True, capture_output=True)
     text = open(asm).read()
     results = {}

@@ -6,7 +6,7 @@ from geocalib_amd import LMOptimizer, _lib
 from geocalib_amd.synth import synth_fields
 dev = torch.device("cuda:0")
 rows = []
-for model in ("pinhole", "simple_radial"):
+for model in ("pinhole", "simple_radial", "radial", "simple_divisional"):
     for (B, H, W) in ((1, 320, 480), (1, 480, 640), (4, 480, 640), (16, 480, 640), (64, 480, 640)):
         d, gtc, _ = synth_fields(model, B, H, W, dev, seed=1)
         for conf, fused in (({"num_steps": 20, "early_stop": False}, 0), ({"num_steps": 20, "early_stop": False}, 1),

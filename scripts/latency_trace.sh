@@ -1,7 +1,8 @@
 #!/bin/bash
-# GPU box: kernel trace of single-image solves (where do the microseconds of a B=1 solve go?).
+# GPU box: kernel trace of single-image solves (where do the microseconds of a B=1 solve go?).  usage: latency_trace.sh [model]
+MODEL=${1:-pinhole}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$REPO/gpurun_out/lat
+OUT=$REPO/gpurun_out/lat_$MODEL
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cat > /tmp/lat1.py <<PY
@@ -10,8 +11,8 @@ import torch
 from geocalib_amd import LMOptimizer
 from geocalib_amd.synth import synth_fields
 dev = torch.device("cuda:0")
-d, _, _ = synth_fields("pinhole", 1, 480, 640, dev, seed=1)
-opt = LMOptimizer({"camera_model": "pinhole"}).eval()
+d, _, _ = synth_fields("$MODEL", 1, 480, 640, dev, seed=1)
+opt = LMOptimizer({"camera_model": "$MODEL"}).eval()
 for _ in range(5):
     out = opt(d); torch.cuda.synchronize()
 PY
@@ -26,7 +27,7 @@ n = len(rows) // 5
 last = rows[-n:]
 t0 = int(last[0]["Start_Timestamp"]); t1 = int(last[-1]["End_Timestamp"])
 busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in last)
-print(f"launches/solve {n}, span {(t1-t0)/1e3:.1f} us, busy {busy/1e3:.1f} us")
+print(f"$MODEL: launches/solve {n}, span {(t1-t0)/1e3:.1f} us, busy {busy/1e3:.1f} us")
 prev = None
 for r in last[:14] + last[-6:]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])

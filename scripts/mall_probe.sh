@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 SIZES=${1:-8,16,24,32,40,64,256}
 for F in "" "-DGCLM_NT_LOADS=0" "-DGCLM_NOMATH=1" "-DGCLM_NOMATH=1 -DGCLM_NT_LOADS=0"; do
   touch geocalib_amd/csrc/gclm_pass.hip geocalib_amd/csrc/gclm_api.hip
-  make -C geocalib_amd/csrc PASS_FLAGS="-fno-slp-vectorize $F" CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast-honor-pragmas -Wall -Wno-unused-function $F" 2>&1 | grep -E "error|warning"
+  make -C geocalib_amd/csrc PASS_FLAGS="$F" CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast-honor-pragmas -Wall -Wno-unused-function $F" 2>&1 | grep -E "error|warning"
   echo "== flags [$F]"
   GCLM_FUSED=0 python scripts/sweep_probe.py pinhole $SIZES
 done

@@ -18,7 +18,7 @@ for m in pinhole simple_radial radial simple_divisional; do
   timeout 300 python scripts/power_probe.py gpurun_out/r03/power_$m.json --tag $m -- --camera-model $m --steps 150 --warmup 2 --repeats 1 2>&1 | tail -1 | cut -c1-700
 done
 touch geocalib_amd/csrc/gclm_pass.hip
-make -C geocalib_amd/csrc PASS_FLAGS="-fno-slp-vectorize -DGCLM_NOMATH=1" 2>&1 | grep -E "error|warning"
+make -C geocalib_amd/csrc PASS_FLAGS="-DGCLM_NOMATH=1" 2>&1 | grep -E "error|warning"
 GCLM_BENCH_NO_CHECK=1 timeout 300 python scripts/power_probe.py gpurun_out/r03/power_nomath.json --tag nomath -- --camera-model pinhole --steps 150 --warmup 2 --repeats 1 2>&1 | tail -1 | cut -c1-700
 touch geocalib_amd/csrc/gclm_pass.hip; make -C geocalib_amd/csrc 2>&1 | grep -E "error|warning"
 echo "=== profiles"

@@ -1483,3 +1483,62 @@ def test_one_launch_per_step_equals_the_two_launch_sequence(dev, model):
     data, _, _ = synth_device(model, 3, 64, 80, dev, seed=2)
     a, b = solve({"camera_model": model}, data, 0), solve({"camera_model": model}, data, 1)
     assert all(np.array_equal(a[k], b[k], equal_nan=True) for k in a)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["pinhole", "simple_divisional"])
+def test_paced_launches_change_how_many_launches_are_issued_and_nothing_else(dev, model):
+    """gclm_set_paced_launches: a single-image solve with early stop issues launch k only after launch k - depth has
+    reported and none after the stop.  Every output stays bit-identical (the device-side skip is what decides), fewer
+    sweeps are issued when the stop comes early, back-to-back solves without a sync in between do not read each other's
+    reports (epoch tag), and the knob is ignored where it cannot help (a batch, early_stop = False, two-launch path)."""
+    import ctypes as C
+    from geocalib_amd import LMOptimizer, _lib
+    lib = _lib.load()
+
+    def solve(conf, data, depth, repeats=1, fused=-1):
+        opt = LMOptimizer(conf).eval()
+        opt.paced_launches = depth
+        h = opt._handle(dev)
+        _lib.check(lib.gclm_set_fused_steps(h.ptr, fused), h.ptr, "gclm_set_fused_steps")
+        opt(data)
+        torch.cuda.synchronize()
+        _lib.check(lib.gclm_set_timing(h.ptr, 1), h.ptr, "gclm_set_timing")
+        outs = [opt(data) for _ in range(repeats)]                      # no sync in between
+        torch.cuda.synchronize()
+        n, ms = C.c_int(0), C.c_float(0)
+        _lib.check(lib.gclm_last_pass_timing(h.ptr, C.byref(n), C.byref(ms)), h.ptr, "gclm_last_pass_timing")
+        return [to_np(o) for o in outs], n.value // repeats
+
+    assert lib.gclm_set_paced_launches(None, 3) == -1
+    probe = LMOptimizer({"camera_model": model})._handle(dev)
+    assert lib.gclm_set_paced_launches(probe.ptr, 17) == -3 and "gclm_set_paced_launches" in _lib.last_error(probe.ptr)
+    assert lib.gclm_set_paced_launches(probe.ptr, 0) == 0
+
+    saved = 0
+    for H, W, extra in ((480, 640, {}), (240, 320, {"atol": 1e-4, "rtol": 1e-4}), (96, 128, {"num_steps": 3}), (96, 128, {"num_steps": 12})):
+        data, _, _ = synth_device(model, 1, H, W, dev, seed=31)
+        conf = {"camera_model": model, **extra}
+        (ref,), n_ref = solve(conf, data, 0)
+        assert n_ref == conf.get("num_steps", 30) + 1                  # one sweep launch per step + the final one
+        for depth in (1, 3, 16):
+            outs, n = solve(conf, data, depth, repeats=4)
+            for o in outs:
+                for k in ref:
+                    assert np.array_equal(ref[k], o[k], equal_nan=True), (model, H, W, extra, depth, k)
+            stop = int(ref["stop_at"][0])
+            assert n <= n_ref and n >= min(stop + 1, n_ref), (n, n_ref, stop)     # never fewer than the device needs
+            if stop + depth + 3 < n_ref:
+                assert n <= stop + depth + 3, (n, stop, depth)                    # the detecting launch, at most depth more, the final one
+                saved += n_ref - n
+    assert saved > 0
+    # ignored: a batch (the stop is batch-global), early_stop = False, the two-launch path
+    data, _, _ = synth_device(model, 2, 96, 128, dev, seed=5)
+    for conf, fused in (({"camera_model": model}, -1), ({"camera_model": model, "early_stop": False, "num_steps": 6}, -1)):
+        (a,), na = solve(conf, data, 0, fused=fused)
+        (b,), nb = solve(conf, data, 3, fused=fused)
+        assert na == nb and all(np.array_equal(a[k], b[k], equal_nan=True) for k in a)
+    data, _, _ = synth_device(model, 1, 96, 128, dev, seed=5)
+    (a,), na = solve({"camera_model": model}, data, 0, fused=0)
+    (b,), nb = solve({"camera_model": model}, data, 3, fused=0)
+    assert na == nb and all(np.array_equal(a[k], b[k], equal_nan=True) for k in a)
