@@ -75,6 +75,9 @@
 #ifndef GCLM_RADIAL_DOT
 #define GCLM_RADIAL_DOT 1           // A/B switch: 0 = radial keeps the explicit-ray latitude block
 #endif
+#ifndef GCLM_BUFFER_AUX
+#define GCLM_BUFFER_AUX -1
+#endif
 #ifndef GCLM_NT_LOADS
 #define GCLM_NT_LOADS 1
 #endif
@@ -733,6 +736,11 @@ struct Lane<4> {
     static constexpr int kPairs = 2;
     static __device__ __forceinline__ V ld(const float* base, uint32_t byte_off) {
         typedef float v4 __attribute__((ext_vector_type(4)));
+#if GCLM_BUFFER_AUX >= 0   // A/B switch: buffer loads with an explicit cache policy (1 = sc0, 2 = nt, 16 = sc1)
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0xffffffffu, 0x00020000);
+        const v4 tb = __builtin_bit_cast(v4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, GCLM_BUFFER_AUX));
+        return make_float4(tb.x, tb.y, tb.z, tb.w);
+#endif
         const v4* p = reinterpret_cast<const v4*>(reinterpret_cast<const char*>(base) + byte_off);
 #if GCLM_NT_LOADS
         // every byte is read exactly once per sweep: stream it past the caches (global_load ... nt)
