@@ -60,6 +60,9 @@ def parse():
                     help="with --shared-group: every GPU owns WHOLE groups (no communication during the solve, one all-gather of "
                          "results) instead of a slice of every group's frames")
     ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--placement-tries", type=int, default=3,
+                    help="allocations of the input fields to choose the fastest-streaming one from, before any timing "
+                         "(geocalib_amd.fields.fastest_placement; 1 = take the first)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="images for the CPU baseline (-1: auto, 0: skip)")
     ap.add_argument("--no-timing", action="store_true", help="skip the in-library HIP-event timing of the sweeps")
     ap.add_argument("--comm", default="torch", choices=["torch", "rccl"],
@@ -155,6 +158,7 @@ def main():
     from geocalib_amd import LMOptimizer, _lib
     from geocalib_amd.parallel import (CollectiveTimer, GatherPlan, RcclComm, SharedIntrinsicsSplit, calibrate_sharded,
                                        frame_split_layout)
+    from geocalib_amd.fields import fastest_placement
     from geocalib_amd.synth import synth_fields
 
     lib = _lib.load()
@@ -167,10 +171,27 @@ def main():
         assert distributed and args.backend == "nccl", "--comm rccl needs a process group to hand out the unique id"
         comm = RcclComm.from_torch_group(local_dev)
     vworld = args.virtual_world or world
+    placement = {"tries": max(args.placement_tries, 1), "solve_ms": None}
+
+    def place(make, optimizer):
+        """The input fields of this rank: the fastest-streaming of --placement-tries allocations (same content; chosen by
+        a LOCAL solve before any timed region, no collective: every rank chooses for its own GPU)."""
+        truth = []
+
+        def allocate():
+            d, c, g = make()
+            truth.append((c, g))
+            return d
+        free_bytes = torch.cuda.mem_get_info(dev)[0]
+        placement["tries"] = max(1, min(placement["tries"], int(0.8 * free_bytes // (B * H * W * PLANES * 4))))   # all candidates are alive at once
+        fields, ms = fastest_placement(allocate, optimizer, placement["tries"])
+        placement["solve_ms"] = [round(t, 3) for t in ms] or None
+        return fields, truth[0][0], truth[0][1]          # the ground truth is the same for every candidate
+
     if gs == 0:
         # independent intrinsics: rank r owns the contiguous images [r*B, (r+1)*B)
-        data, gt_cam, gt_grav = synth_fields(args.camera_model, B, H, W, dev, seed=args.seed, first_index=rank * B)
         opt = LMOptimizer(conf).eval()
+        data, gt_cam, gt_grav = place(lambda: synth_fields(args.camera_model, B, H, W, dev, seed=args.seed, first_index=rank * B), opt)
         ctimer = CollectiveTimer()
         plan = GatherPlan(n_total, world, dev) if distributed else None      # exchange buffers live outside the timed loop
 
@@ -179,8 +200,9 @@ def main():
     elif args.shared_by_group:
         # shared intrinsics sharded by group: rank r owns the groups of the frames [r*B, (r+1)*B); no collective in the solve
         assert B % gs == 0, "the per-GPU batch must hold whole groups"
-        data, gt_cam, gt_grav = synth_fields(args.camera_model, B, H, W, dev, seed=args.seed, first_index=rank * B, group_size=gs)
         opt = LMOptimizer({**conf, "shared_intrinsics": True, "group_size": gs}).eval()
+        data, gt_cam, gt_grav = place(lambda: synth_fields(args.camera_model, B, H, W, dev, seed=args.seed, first_index=rank * B,
+                                                           group_size=gs), opt)
         ctimer = CollectiveTimer()
         plan = GatherPlan(n_total, world, dev) if distributed else None
 
@@ -190,10 +212,10 @@ def main():
         # shared intrinsics: every rank holds gs/world frames of EVERY group (--virtual-world: the shape of a larger run)
         lay = frame_split_layout(B, gs, vworld, rank)
         fpg, n_groups = lay["fpg"], lay["n_groups"]
-        data, gt_cam, gt_grav = synth_fields(args.camera_model, B, H, W, dev, seed=args.seed, first_index=lay["first_index"],
-                                             group_size=gs, run=lay["run"], run_stride=lay["run_stride"])
         # one handle solves what it holds: groups of fpg local frames (= the whole group when it is not split)
         opt = LMOptimizer({**conf, "shared_intrinsics": True, "group_size": fpg}).eval()
+        data, gt_cam, gt_grav = place(lambda: synth_fields(args.camera_model, B, H, W, dev, seed=args.seed, first_index=lay["first_index"],
+                                                           group_size=gs, run=lay["run"], run_stride=lay["run_stride"]), opt)
         ctimer = CollectiveTimer()
         if not distributed:
             def step():
@@ -279,6 +301,8 @@ def main():
                                        f"group-sharded x{world}, one all-gather of results" if args.shared_by_group else
                                        f"frames of every group split x{world}, one all-reduce per LM step")},
             "check": {"median_focal_rel_err_vs_gt": f_err, "median_gravity_abs_err_vs_gt": g_err},
+            "placement": {**placement, "what": "rank 0's input fields were allocated `tries` times before any timing and the "
+                          "allocation whose solve ran fastest was kept (geocalib_amd.fields.fastest_placement, DESIGN.md 3.1)"},
         }
         if distributed:
             result["multi_gpu"] = {

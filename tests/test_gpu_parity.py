@@ -1542,3 +1542,25 @@ def test_paced_launches_change_how_many_launches_are_issued_and_nothing_else(dev
     (a,), na = solve({"camera_model": model}, data, 0, fused=0)
     (b,), nb = solve({"camera_model": model}, data, 3, fused=0)
     assert na == nb and all(np.array_equal(a[k], b[k], equal_nan=True) for k in a)
+
+
+@pytest.mark.gpu
+def test_fastest_placement_returns_one_of_its_candidates(dev):
+    """geocalib_amd.fields.fastest_placement: `tries` allocations alive side by side, each solved twice, the fastest kept;
+    tries <= 1 allocates once and times nothing."""
+    from geocalib_amd import LMOptimizer
+    from geocalib_amd.fields import fastest_placement
+    opt = LMOptimizer({"camera_model": "pinhole", "num_steps": 3, "early_stop": False}).eval()
+    made = []
+
+    def allocate():
+        d, _, _ = synth_device("pinhole", 4, 96, 128, dev, seed=9)
+        made.append(d)
+        return d
+    fields, ms = fastest_placement(allocate, opt, tries=3)
+    assert len(made) == 3 and len(ms) == 3 and all(t > 0 for t in ms)
+    assert fields is made[min(range(3), key=ms.__getitem__)]
+    ptrs = {d["latitude_field"].data_ptr() for d in made}
+    assert len(ptrs) == 3                                       # alive at the same time: three different allocations
+    one, none = fastest_placement(allocate, opt, tries=1)
+    assert none == [] and one is made[3]
