@@ -60,6 +60,7 @@ class _Handle:
         self.key = cfg.key()
         self.device = cfg.device
         self.paced = 0
+        self.signature = None           # LMOptimizer._config_signature the handle was last configured for
 
     def set_paced(self, depth: int):
         if depth != self.paced:
@@ -95,6 +96,8 @@ def _dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
     if not t.is_cuda:
         raise RuntimeError(f"geocalib_amd: `{name}` must live on a HIP device (got {t.device}); "
                            "the MI355X path has no CPU fallback")
+    if t.dtype is torch.float32 and t.is_contiguous() and not t.requires_grad:
+        return t                                   # the common case: nothing to convert (saves three dispatcher trips)
     return t.detach().to(torch.float32).contiguous()
 
 
@@ -209,20 +212,33 @@ class LMOptimizer(nn.Module):
                                       shared_intrinsics: bool = False) -> None:
         """Which parameters are free given the priors in `data` (reference: lm_optimizer.py:189-246)."""
         data = data or {}
-        self.shared_intrinsics = shared_intrinsics
-        self.estimate_gravity = "prior_gravity" not in data
-        self.estimate_focal = "prior_focal" not in data
-        self.estimate_dist = self.camera_has_distortion and "prior_dist" not in data
-        self.gravity_delta_dims = (0, 1) if self.estimate_gravity else (-1,)
-        self.focal_delta_dims = (max(self.gravity_delta_dims) + 1,) if self.estimate_focal else (-1,)
-        self.dist_delta_dims = None
-        if self.estimate_dist:
-            first = self.focal_delta_dims[-1] + 1
-            self.dist_delta_dims = tuple(range(first, first + self.camera_model.num_dist_params()))
-        self.n_intrinsic_params = self.estimate_focal + (
-            self.camera_model.num_dist_params() if self.camera_has_distortion else 0)
+        estimate_gravity = "prior_gravity" not in data
+        estimate_focal = "prior_focal" not in data
+        estimate_dist = self.camera_has_distortion and "prior_dist" not in data
+        gravity_delta_dims = (0, 1) if estimate_gravity else (-1,)
+        focal_delta_dims = (max(gravity_delta_dims) + 1,) if estimate_focal else (-1,)
+        dist_delta_dims = None
+        nd = self.camera_model.num_dist_params() if self.camera_has_distortion else 0
+        if estimate_dist:
+            first = focal_delta_dims[-1] + 1
+            dist_delta_dims = tuple(range(first, first + nd))
+        # plain Python values: written straight into the instance dict (nn.Module.__setattr__ costs ~2 us apiece, and this
+        # runs on every forward -- a quarter of the host time of a single-image solve)
+        self.__dict__.update(shared_intrinsics=shared_intrinsics, estimate_gravity=estimate_gravity,
+                             estimate_focal=estimate_focal, estimate_dist=estimate_dist,
+                             gravity_delta_dims=gravity_delta_dims, focal_delta_dims=focal_delta_dims,
+                             dist_delta_dims=dist_delta_dims, n_intrinsic_params=estimate_focal + nd)
 
     # ------------------------------------------------------------------ C-ABI plumbing
+    def _config_signature(self, device_index: int):
+        """Everything _config() reads, as a tuple that is cheap to build and compare: a handle is only reconfigured (and the
+        ctypes struct only rebuilt) when it changes."""
+        c = self.conf
+        return (device_index, self.camera_model, self.shared_intrinsics, self.num_steps, self.estimate_gravity,
+                self.estimate_focal, self.estimate_dist, self.training, c.group_size, c.lambda_, c.fix_lambda, c.early_stop,
+                c.atol, c.rtol, c.use_spherical_manifold, c.use_log_focal, c.loss_fn, c.up_loss_fn_scale,
+                c.lat_loss_fn_scale, c.init_conf["name"] if isinstance(c.init_conf, dict) else getattr(c.init_conf, "name", "trivial"))
+
     def _config(self, device_index: int = 0) -> _lib.GclmConfig:
         c = self.conf
         name = self.camera_model.name()
@@ -265,11 +281,16 @@ class LMOptimizer(nn.Module):
         """The gclm_handle of (device, stream): solves issued from different torch streams (e.g. the CNN of batch k+1
         overlapping the LM of batch k) get different workspaces; the same stream reuses its own, in order."""
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        cfg = self._config(idx)
         if stream is None:
             stream = torch.cuda.current_stream(torch.device("cuda", idx)).cuda_stream
         key = (idx, int(stream))
+        sig = self._config_signature(idx)
         h = self._handles.pop(key, None)
+        if h is not None and h.signature == sig:         # the common case of a serving loop: nothing to rebuild
+            self._handles[key] = h
+            h.set_paced(int(self.paced_launches))
+            return h
+        cfg = self._config(idx)
         if h is None:
             while len(self._handles) >= self._MAX_HANDLES:      # drop the least recently used (its stream may be gone)
                 old_key = next(iter(self._handles))
@@ -280,6 +301,7 @@ class LMOptimizer(nn.Module):
         else:
             h.configure(cfg)
         self._handles[key] = h            # most recently used last
+        h.signature = sig
         h.set_paced(int(self.paced_launches))
         return h
 
@@ -318,11 +340,12 @@ class LMOptimizer(nn.Module):
 
     def _unpack_info(self, info: torch.Tensor, has_up: bool) -> Dict[str, torch.Tensor]:
         I = _lib.INFO
-        out = {"stop_at": info[:, I["stop_at"]]}
+        col = info.t()              # column k of the packed rows = col[k]: an integer select, the cheapest view there is
+        out = {"stop_at": col[I["stop_at"]]}
         if has_up:
-            out["initial_up_cost"] = info[:, I["initial_up_cost"]]
-        out["initial_latitude_cost"] = info[:, I["initial_latitude_cost"]]
-        out["initial_cost"] = info[:, I["initial_cost"]]
+            out["initial_up_cost"] = col[I["initial_up_cost"]]
+        out["initial_latitude_cost"] = col[I["initial_latitude_cost"]]
+        out["initial_cost"] = col[I["initial_cost"]]
         if not self.training:
             P = (2 * self.estimate_gravity + self.estimate_focal
                  + (self.camera_model.num_dist_params() if self.camera_has_distortion else 0))
@@ -330,12 +353,12 @@ class LMOptimizer(nn.Module):
             out["covariance"] = info[:, c0:c0 + P * P].reshape(-1, P, P)
             for k in ("roll_uncertainty", "pitch_uncertainty", "gravity_uncertainty", "focal_uncertainty",
                       "vfov_uncertainty"):
-                out[k] = info[:, I[k]]
+                out[k] = col[I[k]]
         if has_up:
-            out["final_up_cost"] = info[:, I["final_up_cost"]]
-        out["final_latitude_cost"] = info[:, I["final_latitude_cost"]]
-        out["final_cost"] = info[:, I["final_cost"]]
-        out["step_failures"] = info[:, I["step_failures"]]
+            out["final_up_cost"] = col[I["final_up_cost"]]
+        out["final_latitude_cost"] = col[I["final_latitude_cost"]]
+        out["final_cost"] = col[I["final_cost"]]
+        out["step_failures"] = col[I["step_failures"]]
         return out
 
     def forward(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
@@ -385,7 +408,8 @@ class LMOptimizer(nn.Module):
         if B > self._MAX_CALL:
             return self._calibrate_chunked(data, B)
         device = lat.device
-        h = self._handle(device)
+        stream = torch.cuda.current_stream(device).cuda_stream      # looked up once: the handle's key and the launch stream
+        h = self._handle(device, stream)
 
         def prior(key, shape):
             if key not in data:
@@ -407,12 +431,11 @@ class LMOptimizer(nn.Module):
         cam = torch.empty((B, 8), dtype=torch.float32, device=device)
         grav = torch.empty((B, 3), dtype=torch.float32, device=device)
         info = torch.empty((B, _lib.INFO_STRIDE), dtype=torch.float32, device=device)
-        with torch.cuda.device(device):
-            stream = torch.cuda.current_stream(device).cuda_stream
-            P = self._ptr
-            rc = _lib.load().gclm_calibrate(h.ptr, P(up), P(lat), P(upc), P(latc), B, H, W, P(scales), P(pf), P(pg),
-                                            P(pd), nd, cam.data_ptr(), grav.data_ptr(), info.data_ptr(), stream)
-        _lib.check(rc, h.ptr, "gclm_calibrate")
+        P = self._ptr           # (the library switches to the handle's device itself: no torch.cuda.device() context)
+        rc = _lib.load().gclm_calibrate(h.ptr, P(up), P(lat), P(upc), P(latc), B, H, W, P(scales), P(pf), P(pg),
+                                        P(pd), nd, cam.data_ptr(), grav.data_ptr(), info.data_ptr(), stream)
+        if rc != 0:
+            _lib.check(rc, h.ptr, "gclm_calibrate")
         self._last_raw = (cam, grav, info)
         return self.camera_model(cam), _unit_gravity(grav), self._unpack_info(info, up is not None)
 
