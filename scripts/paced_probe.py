@@ -6,6 +6,10 @@ from geocalib_amd import LMOptimizer
 from geocalib_amd.synth import synth_fields
 dev = torch.device("cuda:0")
 rows = []
+_d, _, _ = synth_fields("pinhole", 1, 480, 640, dev, seed=1)          # the process's first few hundred launches are slower: not measured
+_o = LMOptimizer({"camera_model": "pinhole"}).eval()
+for _ in range(300): _o(_d)
+torch.cuda.synchronize()
 for model in ("pinhole", "simple_radial", "radial", "simple_divisional"):
     for (H, W) in ((320, 480), (480, 640)):
         d, _, _ = synth_fields(model, 1, H, W, dev, seed=1)
