@@ -1,0 +1,50 @@
+"""CPU: what the compiler made of the kernels, read from the code objects inside the built library.
+
+Round 3 found a 4 KB LDS array nobody wrote in every `simple_divisional` sweep: LLVM's VectorCombine had pinned four
+parameter-block fields in a private array, AMDGPUPromoteAlloca moved it to LDS indexed by the flat thread id, and the flat
+thread id cost every wave a read of the dispatch packet in host memory (28 us per single-image launch instead of 10;
+DESIGN.md 3.1).  Nothing in the sources shows such a thing, so the build is audited: LDS and scratch of every sweep
+instantiation must be what the source asks for."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "geocalib_amd", "lib", "libgeocalib_hip.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def kernel_metadata(tmp_path):
+    shutil.copy(SO, tmp_path / "lib.so")
+    subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", "lib.so"], cwd=tmp_path, check=True, capture_output=True)
+    kernels = {}
+    for f in sorted(os.listdir(tmp_path)):
+        if "amdgcn" not in f:
+            continue
+        notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", f], cwd=tmp_path, check=True, capture_output=True,
+                               text=True).stdout
+        for m in re.finditer(r"\.group_segment_fixed_size:\s*(\d+)\s*\n(?:.*\n)*?\s*\.name:\s*(\S+)\s*\n(?:.*\n)*?\s*"
+                             r"\.private_segment_fixed_size:\s*(\d+)\s*\n(?:.*\n)*?\s*\.vgpr_count:\s*(\d+)", notes):
+            kernels[m.group(2)] = {"lds": int(m.group(1)), "scratch": int(m.group(3)), "vgpr": int(m.group(4))}
+    return kernels
+
+
+@pytest.mark.skipif(not (os.path.exists(SO) and os.path.exists(f"{LLVM}/llvm-readelf")), reason="library or LLVM tools missing")
+def test_no_sweep_kernel_carries_an_lds_array_or_scratch_it_was_not_given(tmp_path):
+    k = kernel_metadata(tmp_path)
+    sweeps = {n: v for n, v in k.items() if "sweep_kernelILi" in n}
+    fused = {n: v for n, v in k.items() if "fused_step_kernelILi" in n}
+    assert len(sweeps) >= 48 and len(fused) >= 32, (len(sweeps), len(fused))
+    # the sweep's only LDS is the 4-wave reduction buffer (4 x NACC floats: 256 B; radial 384 B)
+    assert all(v["lds"] <= 384 for v in sweeps.values()), {n: v for n, v in sweeps.items() if v["lds"] > 384}
+    # the one-launch-per-step kernels add the update prologue's buffers (stripes of the record reduction, parameter block)
+    assert all(v["lds"] <= 2816 for v in fused.values()), {n: v for n, v in fused.items() if v["lds"] > 2816}
+    # scratch: none, except the two general-focal simple_divisional instantiations held to 168 VGPRs (8 B)
+    spilling = {n: v["scratch"] for n, v in {**sweeps, **fused}.items() if v["scratch"]}
+    assert all("ILi3E" in n and "Lb0ELi4E" in n and s <= 16 for n, s in spilling.items()) and len(spilling) <= 2, spilling
+    # the BASELINE instantiations keep their occupancy: pinhole 80 VGPRs (6 waves / SIMD), simple_radial <= 128 (4 waves)
+    main = {m: next(v for n, v in sweeps.items() if f"sweep_kernelILi{m}ELb1ELb1ELb1ELb1ELi4E" in n) for m in range(4)}
+    assert main[0]["vgpr"] <= 80 and main[1]["vgpr"] <= 128 and main[2]["vgpr"] <= 168 and main[3]["vgpr"] <= 168, main
