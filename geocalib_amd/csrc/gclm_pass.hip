@@ -75,6 +75,9 @@
 #ifndef GCLM_RADIAL_DOT
 #define GCLM_RADIAL_DOT 1           // A/B switch: 0 = radial keeps the explicit-ray latitude block
 #endif
+#ifndef GCLM_FENCE_PROBE
+#define GCLM_FENCE_PROBE 0
+#endif
 #ifndef GCLM_BUFFER_AUX
 #define GCLM_BUFFER_AUX -1
 #endif
@@ -915,6 +918,19 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const PBlock& P, 
         if (tid == A_CL) s *= hk.a2l;
         a.partials[((size_t)b * a.nchunks + chunk) * NACC + tid] = s;
     }
+#if GCLM_FENCE_PROBE   // measurement only: what a "last workgroup of the image runs the update" scheme would pay per workgroup
+    // (release the record, count the image's finished workgroups with an agent-scope RMW; the counters live behind the records)
+    __syncthreads();
+    if (tid == 0) {
+        int* cnt = reinterpret_cast<int*>(a.partials + (size_t)a.B * a.nchunks * NACC) + b;
+#if GCLM_FENCE_PROBE == 1
+        const int seen = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        const int seen = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+        if (seen == 0x7fffffff) a.partials[0] = 0.f;      // never: keeps the RMW's result alive
+    }
+#endif
 }
 
 // launch bounds: radial / simple_divisional are held to 168 VGPRs (3 waves per SIMD); simple_radial reaches 112 (4 waves)
