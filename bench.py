@@ -60,7 +60,7 @@ def parse():
                     help="with --shared-group: every GPU owns WHOLE groups (no communication during the solve, one all-gather of "
                          "results) instead of a slice of every group's frames")
     ap.add_argument("--seed", type=int, default=2024)
-    ap.add_argument("--placement-tries", type=int, default=3,
+    ap.add_argument("--placement-tries", type=int, default=4,
                     help="allocations of the input fields to choose the fastest-streaming one from, before any timing "
                          "(geocalib_amd.fields.fastest_placement; 1 = take the first)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="images for the CPU baseline (-1: auto, 0: skip)")
