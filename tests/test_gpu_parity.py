@@ -1564,3 +1564,47 @@ def test_fastest_placement_returns_one_of_its_candidates(dev):
     assert len(ptrs) == 3                                       # alive at the same time: three different allocations
     one, none = fastest_placement(allocate, opt, tries=1)
     assert none == [] and one is made[3]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["pinhole", "simple_radial"])
+def test_overlap_streams_equals_the_single_call(dev, model):
+    """LMOptimizer.overlap_streams: a batch of independent images with a fixed step count solved as n contiguous parts on
+    n side streams (fork / join by events).  Every output equals the single call's bit for bit when the parts are cut like
+    the whole batch (here: >= 256 images of 640x480 per part), with an uneven split and per-image priors as well; the knob
+    is ignored with early_stop (one decision over the whole batch), shared intrinsics and parts below 256 images."""
+    from geocalib_amd import LMOptimizer
+    B, H, W = 513, 480, 640
+    data, gt_cam, _ = synth_device(model, B, H, W, dev, seed=3)
+
+    def solve(conf, d, n):
+        opt = LMOptimizer({"camera_model": model, **conf}).eval()
+        opt.overlap_streams = n
+        out = opt(d)
+        out2 = opt(d)                                     # side streams and their handles are reused
+        torch.cuda.synchronize()
+        a, b = to_np(out), to_np(out2)
+        assert all(np.array_equal(a[k], b[k], equal_nan=True) for k in a)
+        return a, opt
+
+    fixed = {"num_steps": 4, "early_stop": False}
+    one, _ = solve(fixed, data, 1)
+    two, opt2 = solve(fixed, data, 2)
+    assert opt2._overlap_parts(B) == 2 and len(opt2._handles) >= 2
+    for k in one:
+        assert np.array_equal(one[k], two[k], equal_nan=True), (model, k)
+    eight, opt8 = solve(fixed, data, 8)                                   # capped: 513 // 256 = 2 parts
+    assert opt8._overlap_parts(B) == 2
+    assert all(np.array_equal(one[k], eight[k], equal_nan=True) for k in one)
+    withp = {**data, "prior_focal": gt_cam[:, 3].contiguous()}
+    p1, _ = solve(fixed, withp, 1)
+    p2, _ = solve(fixed, withp, 2)
+    assert all(np.array_equal(p1[k], p2[k], equal_nan=True) for k in p1)
+    # ignored: early stop, shared intrinsics
+    assert LMOptimizer({"camera_model": model})._overlap_parts(B) == 1
+    sh = LMOptimizer({"camera_model": model, "shared_intrinsics": True, "early_stop": False})
+    sh.overlap_streams = 2
+    assert sh._overlap_parts(B) == 1
+    small = LMOptimizer({"camera_model": model, "early_stop": False})
+    small.overlap_streams = 2
+    assert small._overlap_parts(300) == 1 and small._overlap_parts(512) == 2
