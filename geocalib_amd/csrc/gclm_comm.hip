@@ -21,7 +21,7 @@ struct gclm_comm {
 };
 
 namespace {
-std::string g_comm_error;
+thread_local std::string g_comm_error;
 int cfail(gclm_comm* c, int code, const char* what, const char* detail) {
     std::string m = std::string(what) + ": " + detail;
     if (c) c->err = m; else g_comm_error = m;
@@ -38,10 +38,29 @@ int gclm_comm_unique_id(void* id_out) {
     return r == ncclSuccess ? 0 : cfail(nullptr, -20, "ncclGetUniqueId", ncclGetErrorString(r));
 }
 
+int gclm_comm_versions(int* compiled, int* runtime) {
+    // Which librccl answers is decided by the dynamic loader: this library names /opt/rocm/lib/librccl.so.1 (RUNPATH), but a
+    // process that has already loaded another librccl with the same soname (a torch process: torch/lib/librccl.so) keeps
+    // that one.  Both are reported so that the caller can see which pair is running.
+    int rt = 0;
+    if (ncclGetVersion(&rt) != ncclSuccess) rt = 0;
+    if (compiled) *compiled = NCCL_VERSION_CODE;
+    if (runtime) *runtime = rt;
+    return 0;
+}
+
 int gclm_comm_create(gclm_comm** out, const void* unique_id, int nranks, int rank, int device) {
     if (!out || !unique_id || nranks <= 0 || rank < 0 || rank >= nranks)
         return cfail(nullptr, -1, "gclm_comm_create", "bad arguments");
     *out = nullptr;
+    // the three entry points used here (ncclCommInitRank / ncclAllGather / ncclAllReduce) are stable within a major
+    // version; a librccl of another major version must not be driven through this header's declarations
+    int rt = 0;
+    if (ncclGetVersion(&rt) != ncclSuccess || rt / 10000 != NCCL_VERSION_CODE / 10000) {
+        std::string m = "librccl at run time reports version " + std::to_string(rt) + ", this library was compiled against " +
+                        std::to_string(NCCL_VERSION_CODE) + " (major versions differ)";
+        return cfail(nullptr, -21, "gclm_comm_create", m.c_str());
+    }
     if (hipSetDevice(device) != hipSuccess) return cfail(nullptr, -10, "gclm_comm_create", "hipSetDevice failed");
     gclm_comm* c = new (std::nothrow) gclm_comm();
     if (!c) return cfail(nullptr, -12, "gclm_comm_create", "out of host memory");
