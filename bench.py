@@ -7,17 +7,23 @@ for N>1 by the single RCCL all-gather of the packed results.  Inputs are generat
 before the timed region (counter-based generator keyed by (seed, global image index)).
 
     python bench.py                      # N=1
+    python bench.py --gpus N             # N>1 without a launcher: re-executes itself under torch.distributed.run
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline:     achieved = algorithmic bytes of one sweep launch / mean sweep duration measured with
                 HIP events on the launch stream inside the timed region; peak = 8 TB/s HBM3E.
-  cpu_baseline: the CPU oracle (oracle/lm_oracle.c, a port of the reference algorithm) on a bounded
-                sample of the same workload, on this box's host cores (rank 0, N=1 only), and beside it
-                `reference_torch`: the reference's OWN PyTorch CPU path (geocalib/lm_optimizer.py:141, .eval(),
-                no_grad), measured where the reference exists -- the build container -- by
-                scripts/cpu_reference_torch.py and read from profiles/cpu_reference_torch.json (hardware named).
+  cpu_baseline: rank 0, N=1 only, on a bounded sample of the timed batch, on THIS box's host cores.  Where the reference
+                checkout exists on the box ($GEOCALIB_REFERENCE or /root/reference): the reference's OWN PyTorch CPU path
+                (geocalib/lm_optimizer.py:141, .eval(), no_grad) is timed -- kind "reference", measured_on "this box" --
+                with the CPU oracle (oracle/lm_oracle.c, a port) beside it as `port`.  Where it does not (the GPU box):
+                the port is the baseline (kind "port", reference_on_this_box false) and `reference_torch` carries the
+                reference's timing from the build container (profiles/cpu_reference_torch.json, hardware named).
+  secondary:    N=1 default run only: BASELINE configs[3] (simple_radial, B=1024) and configs[4]'s shape (shared intrinsics,
+                64 groups x 16 frames) at 5 steps after 2 warm-ups each, same event-based sweep timing and ground-truth check.
+  overlap:      N=1, independent intrinsics: the same batch solved as two halves on two side streams
+                (LMOptimizer.overlap_streams = 2, the library's default for large batches); `value` stays the one-stream run.
 The timed region (exactly --steps steps between barrier + synchronize) is run --repeats times; `value` and
 `ms_per_step` are the MEDIAN region (a 0.2-0.4 s window has a few % of run-to-run variance), all regions are listed.
 For N > 1 the line also carries `multi_gpu`: ranks_seen (from the communicator), per_rank_ms (every rank's own
@@ -69,6 +75,9 @@ def parse():
                     help="allocations of the input fields to choose the fastest-streaming one from, before any timing "
                          "(geocalib_amd.fields.fastest_placement; 1 = take the first)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="images for the CPU baseline (-1: auto, 0: skip)")
+    ap.add_argument("--no-secondary", dest="secondary", action="store_false",
+                    help="N=1 pinhole run: skip the `secondary` records (configs[3] simple_radial, configs[4] shared-16 shape)")
+    ap.add_argument("--no-overlap", action="store_true", help="N=1: skip the `overlap` record (the batch as two halves on two streams)")
     ap.add_argument("--no-timing", action="store_true", help="skip the in-library HIP-event timing of the sweeps")
     ap.add_argument("--comm", default="torch", choices=["torch", "rccl"],
                     help="route of the two data-path collectives: torch.distributed (nccl = RCCL) or RCCL directly behind "
@@ -81,24 +90,63 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(args, n_images, device_data):
-    """Oracle (C port of the reference algorithm, OpenMP over images) on a bounded sample: the FIRST n images of the very
-    batch the GPU was timed on, copied to the host (the checker runs after the timed region, on rank 0 at N = 1 only)."""
-    from oracle import lm_oracle
+def cpu_baseline(args, n_images, host_data):
+    """The CPU baseline on a bounded sample: the FIRST n images of the very batch the GPU was timed on, already copied to
+    the host (numpy, float32).  Runs after the timed region, on rank 0 at N = 1 only.
+
+    The port (oracle/lm_oracle.c: a C restatement of the reference algorithm, OpenMP over images) is always timed.  Where
+    the reference checkout exists on THIS box ($GEOCALIB_REFERENCE, default /root/reference) the reference's own PyTorch
+    path is timed too, on the first `ref_images` of the same sample, and becomes the baseline of record
+    (kind "reference", measured_on "this box") with the port beside it."""
+    from oracle import lm_oracle, ref_import
     cores = lm_oracle.effective_cpus()        # what the cgroup grants, not what the box has
     lm_oracle.build()
-    data = {k: v[:n_images].cpu().numpy() for k, v in device_data.items()}
+    data = {k: v[:n_images] for k, v in host_data.items()}
     conf = {"camera_model": args.camera_model, "num_steps": args.lm_steps, "early_stop": False}
     t0 = time.perf_counter()
     lm_oracle.solve(data, conf, precision="f32", num_threads=cores)
     dt = time.perf_counter() - t0
-    out = {"value": round(n_images / dt, 3), "unit": "images/sec", "cores": min(cores, n_images), "kind": "port",
-           "sample": f"the first {n_images} images of the timed batch ({args.width}x{args.height}), {args.lm_steps} LM iters, "
-                     f"oracle/lm_oracle.c (float32, OpenMP over images), {dt:.1f} s"}
+    port = {"value": round(n_images / dt, 3), "unit": "images/sec", "cores": min(cores, n_images), "kind": "port",
+            "sample": f"the first {n_images} images of the timed batch ({args.width}x{args.height}), {args.lm_steps} LM iters, "
+                      f"oracle/lm_oracle.c (float32, OpenMP over images), {dt:.1f} s"}
+    if ref_import.available():
+        try:
+            ref = reference_on_this_box(args, data, cores)
+            return {**ref, "reference_on_this_box": True, "port": port}
+        except Exception as e:      # an incomplete checkout must not take the baseline down: say so and keep the port
+            port["reference_error"] = repr(e)
+    out = {**port, "reference_on_this_box": False}
     ref = reference_torch(args)
     if ref is not None:
         out["reference_torch"] = ref
     return out
+
+
+def reference_on_this_box(args, data, cores, ref_images=8):
+    """The reference's own LMOptimizer (geocalib/lm_optimizer.py:141; .eval(), torch.no_grad(), CPU float32,
+    torch.set_num_threads(cores)) on the first `ref_images` images of the sample, as ONE batch (the reference materialises
+    (B,N,2,P) Jacobians: several GB at B = 8 of 640x480), after one untimed single-image warm-up."""
+    from oracle import ref_import
+    ref = ref_import.load()
+    n = min(ref_images, next(iter(data.values())).shape[0])
+    prev = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    try:
+        opt = ref.lm_optimizer.LMOptimizer({"camera_model": args.camera_model, "num_steps": args.lm_steps,
+                                            "early_stop": False}).eval()
+        td = {k: torch.from_numpy(v[:n].copy()) for k, v in data.items()}
+        with torch.no_grad():
+            opt({k: v[:1] for k, v in td.items()})             # warm-up: thread pool, allocator
+            t0 = time.perf_counter()
+            opt(td)
+            dt = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(prev)
+    return {"value": round(n / dt, 4), "unit": "images/sec", "cores": cores, "kind": "reference", "measured_on": "this box",
+            "code": f"{ref_import.REFERENCE_ROOT}/geocalib/lm_optimizer.py:141 LMOptimizer, .eval(), torch.no_grad(), CPU float32, "
+                    f"torch {torch.__version__}, {cores} threads",
+            "sample": f"the first {n} images of the timed batch ({args.width}x{args.height}) as one batch, {args.lm_steps} LM "
+                      f"iters, {dt:.1f} s"}
 
 
 def reference_torch(args):
@@ -117,6 +165,62 @@ def reference_torch(args):
             "measured_on": f"{r['host']}: {r['cpu']}, {r['cores']} threads, torch {r['torch']}",
             "sample": f"{m['images']} images {r['width']}x{r['height']} in chunks of {r['chunk']}, {r['lm_steps']} LM iters, "
                       f"{m['seconds']} s", "source": "profiles/cpu_reference_torch.json"}
+
+
+def quick_case(lib, LMOptimizer, synth_fields, dev, model, B, H, W, lm_steps, seed, group, steps=5, warmup=2):
+    """One secondary record: `steps` solves after `warmup`, first allocation, one stream; sweep launches timed with the
+    library's HIP events, result checked against the synthetic ground truth like the headline."""
+    conf = {"camera_model": model, "num_steps": lm_steps, "early_stop": False}
+    if group:
+        conf.update(shared_intrinsics=True, group_size=group)
+    opt = LMOptimizer(conf).eval()
+    opt.overlap_streams = 1
+    data, gt_cam, gt_grav = synth_fields(model, B, H, W, dev, seed=seed, group_size=group or 1)
+    for _ in range(warmup):
+        out = opt(data)
+    torch.cuda.synchronize()
+    h = opt._handle(dev)
+    lib.gclm_set_timing(h.ptr, 1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = opt(data)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n, ms = C.c_int(0), C.c_float(0)
+    lib.gclm_last_pass_timing(h.ptr, C.byref(n), C.byref(ms))
+    lib.gclm_set_timing(h.ptr, 0)
+    f_err = (out["camera"]._data[:, 3] / gt_cam[:, 3] - 1).abs().median().item()
+    g_err = (out["gravity"]._data - gt_grav).abs().max(1).values.median().item()
+    assert f_err < 5e-3 and g_err < 5e-3, (model, group, f_err, g_err)
+    avg_ms = ms.value / max(n.value, 1)
+    bytes_per_launch = B * H * W * PLANES * 4
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+    value = B * steps / dt
+    rec = {"workload": (f"BASELINE configs[3]: batch={B}, {model}" if not group else
+                        f"BASELINE configs[4] shape: shared intrinsics, {B // group} groups x {group} frames, {model}") +
+                       f", synthetic {W}x{H}, {lm_steps} LM iters + final/uncertainty sweep, early_stop=False",
+           "value": round(value, 1), "unit": "images/sec" if not group else "frames/sec", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(dt / steps * 1e3, 4),
+           "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "avg_launch_ms": round(avg_ms, 4), "launches_timed": n.value,
+                        "whole_job_frac": round(value * (lm_steps + 1) * H * W * PLANES * 4 / 1e9 / HBM_PEAK_GBS, 4)},
+           "check": {"median_focal_rel_err_vs_gt": f_err, "median_gravity_abs_err_vs_gt": g_err},
+           "placement": "first allocation (no choice among allocations)"}
+    del data, out
+    torch.cuda.empty_cache()
+    return rec
+
+
+def rccl_versions(lib):
+    """NCCL_VERSION_CODE libgeocalib_hip.so was compiled against, ncclGetVersion() of the librccl this process bound
+    (inside a torch process: torch's own librccl.so, loaded first, same soname), and torch's view of the same."""
+    comp, run = C.c_int(0), C.c_int(0)
+    lib.gclm_comm_versions(C.byref(comp), C.byref(run))
+    try:
+        tv = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:
+        tv = None
+    return {"compiled": comp.value, "runtime": run.value, "torch": tv}
 
 
 def ensure_built(local_rank: int) -> None:
@@ -138,15 +242,72 @@ def ensure_built(local_rank: int) -> None:
     time.sleep(2.0)      # let the linker finish writing
 
 
+_RESULT_FD = None
+
+
+def claim_stdout():
+    """stdout carries ONE line.  Libraries below us write there too (gloo: "[Gloo] Rank 0 is connected to ...", RCCL's
+    banner), so file descriptor 1 is pointed at stderr for the life of the process and the JSON line goes to a private
+    duplicate of the original stdout."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj) -> None:
+    line = (json.dumps(obj) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, line)
+
+
+def fail_line(args, message: str, code: int = 2):
+    """ONE JSON line that says why there is no measurement (instead of a traceback), and a non-zero exit."""
+    emit({"metric": "images/sec LM calibration (640x480, 20 iters)", "value": None, "unit": "images/sec",
+          "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "error": message})
+    raise SystemExit(code)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU) under
+    torch.distributed.run on 127.0.0.1 with a free port, same arguments.  The children inherit stdout, rank 0 prints
+    the ONE JSON line; the launcher's own chatter goes to stderr."""
+    import socket
+    import subprocess
+    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if visible == 0:
+        fail_line(args, "no HIP device is visible (bench.py has no CPU fallback for the product path)")
+    if args.backend == "nccl" and visible < args.gpus:        # (gloo test rigs let ranks share a GPU)
+        fail_line(args, f"--gpus {args.gpus} but only {visible} HIP device(s) visible: RCCL needs one GPU per rank")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, GCLM_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("OMP_NUM_THREADS", "1")               # (what torchrun would set, without its warning)
+    # the children write their ONE line to our stdout (the private duplicate); whatever else they print goes to stderr
+    raise SystemExit(subprocess.run(cmd, env=env, stdout=_RESULT_FD if _RESULT_FD is not None else None).returncode)
+
+
 def main():
     args = parse()
+    claim_stdout()
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("GCLM_FORCE_COLLECTIVES") == "1"):
+        self_launch(args)       # (GCLM_FORCE_COLLECTIVES=1 with --gpus 1: the N>1 code path through RCCL with one rank)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
+    if args.gpus != world and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); measuring {world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        if rank == 0:
+            fail_line(args, "no HIP device is visible (bench.py has no CPU fallback for the product path)")
+        raise SystemExit(2)
     local_dev = local_rank % torch.cuda.device_count()      # one rank per GPU; test rigs with fewer GPUs than ranks share them
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
@@ -177,6 +338,7 @@ def main():
         comm = RcclComm.from_torch_group(local_dev)
     vworld = args.virtual_world or world
     placement = {"tries": max(args.placement_tries, 1), "solve_ms": None}
+    first_fields = []                 # the first allocation's fields (N = 1: timed beside the chosen one)
 
     def place(make, optimizer):
         """The input fields of this rank: the fastest-streaming of --placement-tries allocations (same content; chosen by
@@ -189,13 +351,17 @@ def main():
             return d
         free_bytes = torch.cuda.mem_get_info(dev)[0]
         placement["tries"] = max(1, min(placement["tries"], int(0.8 * free_bytes // (B * H * W * PLANES * 4))))   # all candidates are alive at once
-        fields, ms = fastest_placement(allocate, optimizer, placement["tries"])
+        fields, ms, first = fastest_placement(allocate, optimizer, placement["tries"], keep_first=True)
         placement["solve_ms"] = [round(t, 3) for t in ms] or None
+        placement["chosen"] = ms.index(min(ms)) if ms else 0
+        if world == 1 and placement["chosen"] != 0:
+            first_fields.append(first)
         return fields, truth[0][0], truth[0][1]          # the ground truth is the same for every candidate
 
     if gs == 0:
         # independent intrinsics: rank r owns the contiguous images [r*B, (r+1)*B)
         opt = LMOptimizer(conf).eval()
+        opt.overlap_streams = 1            # the line of record is the one-stream solve (--streams / the `overlap` block: two)
         data, gt_cam, gt_grav = place(lambda: synth_fields(args.camera_model, B, H, W, dev, seed=args.seed, first_index=rank * B), opt)
         ctimer = CollectiveTimer()
         plan = GatherPlan(n_total, world, dev) if distributed else None      # exchange buffers live outside the timed loop
@@ -300,6 +466,55 @@ def main():
     if os.environ.get("GCLM_BENCH_NO_CHECK") != "1":      # only the -DGCLM_NOMATH=1 measurement build (memory ceiling) skips this
         assert f_err < 5e-3 and g_err < 5e-3, (f_err, g_err)
 
+    def timed_regions(fn, repeats):
+        """median seconds of `repeats` regions of --steps calls of fn (single process: no barrier)"""
+        rs = []
+        for _ in range(repeats):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                fn()
+            torch.cuda.synchronize()
+            rs.append(time.perf_counter() - t0)
+        return sorted(rs)[len(rs) // 2]
+
+    extras = {}
+    solo = world == 1 and not distributed and gs == 0 and not overlapped
+    if solo:
+        lib.gclm_set_timing(handle.ptr, 0)
+        if first_fields:
+            # what a caller who allocates ONCE gets on this box: the same steps on the first allocation's fields
+            opt(first_fields[0])
+            sec = timed_regions(lambda: opt(first_fields[0]), 1)
+            placement["first_allocation"] = {"value": round(B * args.steps / sec, 1), "ms_per_step": round(sec / args.steps * 1e3, 4)}
+            first_fields.clear()
+        if not args.no_overlap and B >= 512:
+            # the library's default for a batch this large: two halves on two side streams, one part's update launches
+            # under the other's sweep (LMOptimizer.overlap_streams); results must be the one-stream solve's, bit for bit
+            one = [t.clone() for t in opt._last_raw]
+            opt.overlap_streams = 2
+            for _ in range(2):
+                opt(data)
+            same = all(torch.equal(a, b) for a, b in zip(one, opt._last_raw))
+            sec = timed_regions(lambda: opt(data), max(args.repeats, 1))
+            opt.overlap_streams = 1
+            v2 = B * args.steps / sec
+            extras["overlap"] = {"streams": 2, "value": round(v2, 1), "ms_per_step": round(sec / args.steps * 1e3, 4),
+                                 "bit_identical": bool(same),
+                                 "whole_job_frac": round(v2 * (args.lm_steps + 1) * H * W * PLANES * 4 / 1e9 / HBM_PEAK_GBS, 4)}
+    host_sample = None
+    if rank == 0 and world == 1 and args.cpu_sample != 0 and gs == 0:
+        from oracle.lm_oracle import effective_cpus
+        n_cpu = min(B, args.cpu_sample if args.cpu_sample > 0 else max(8, 16 * effective_cpus()))   # ~7-10 s of CPU work
+        host_sample = {k: v[:n_cpu].cpu().numpy() for k, v in data.items()}
+    if solo and args.secondary and args.camera_model == "pinhole":
+        del data, out
+        torch.cuda.empty_cache()
+        extras["secondary"] = {
+            f"simple_radial_B{B}": quick_case(lib, LMOptimizer, synth_fields, dev, "simple_radial", B, H, W, args.lm_steps, args.seed, 0),
+            "shared16_pinhole": quick_case(lib, LMOptimizer, synth_fields, dev, "pinhole", B, H, W, args.lm_steps, args.seed, 16),
+        }
+
     if rank == 0:
         value = n_total * args.steps / elapsed
         algo_bytes_per_launch = B * H * W * PLANES * 4
@@ -327,8 +542,11 @@ def main():
                                        f"frames of every group split x{world}, one all-reduce per LM step")},
             "check": {"median_focal_rel_err_vs_gt": f_err, "median_gravity_abs_err_vs_gt": g_err},
             "placement": {**placement, "what": "rank 0's input fields were allocated `tries` times before any timing and the "
-                          "allocation whose solve ran fastest was kept (geocalib_amd.fields.fastest_placement, DESIGN.md 3.1)"},
+                          "allocation whose solve ran fastest was kept (geocalib_amd.fields.fastest_placement, DESIGN.md 3.1): "
+                          "`value` is measured on the CHOSEN allocation, `first_allocation` (N = 1; absent when the first one "
+                          "was chosen) is the same measurement on the first"},
         }
+        result.update(extras)
         if distributed:
             result["multi_gpu"] = {
                 "ranks_seen": ranks_seen, "per_rank_ms": per_rank_ms,
@@ -340,7 +558,10 @@ def main():
                 "collective_ms": round(coll_ms_max, 4), "backend": args.backend,
                 "comm": ("gclm_comm_* (RCCL behind the C ABI, on the solve's stream)" if comm is not None
                          else "torch.distributed"),
-                "virtual_world": vworld if vworld != world else None}
+                "virtual_world": vworld if vworld != world else None,
+                "launched_by": "bench.py itself (torch.distributed.run child)" if os.environ.get("GCLM_BENCH_SELF_LAUNCHED") == "1"
+                               else "an external launcher",
+                "rccl": rccl_versions(lib)}
         if sweep_n:
             avg_ms = sweep_ms / sweep_n
             achieved = algo_bytes_per_launch / (avg_ms * 1e-3) / 1e9
@@ -362,14 +583,12 @@ def main():
                                 f"solve {args.streams} parts of the batch concurrently, whose launch durations overlap and are "
                                 "not separable" if overlapped else "the timed regions"),
                 "whole_job_frac": round(value / world * (args.lm_steps + 1) * H * W * PLANES * 4 / 1e9 / HBM_PEAK_GBS, 4)}
-        if world == 1 and args.cpu_sample != 0 and gs == 0:      # (the port times independent solves: configs[1] / [3])
-            from oracle.lm_oracle import effective_cpus
-            n = min(B, args.cpu_sample if args.cpu_sample > 0 else max(8, 16 * effective_cpus()))   # ~7-10 s of CPU work
+        if host_sample is not None:      # (the baselines time independent solves: configs[1] / [3])
             try:
-                result["cpu_baseline"] = cpu_baseline(args, n, data)
+                result["cpu_baseline"] = cpu_baseline(args, next(iter(host_sample.values())).shape[0], host_sample)
             except Exception as e:  # the checker must never take the product measurement down
                 result["cpu_baseline"] = {"value": None, "error": repr(e)}
-        print(json.dumps(result), flush=True)
+        emit(result)
     if distributed:
         dist.destroy_process_group()
 

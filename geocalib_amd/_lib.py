@@ -16,7 +16,7 @@ INFO_STRIDE = 48
 SHARED_PARTIAL_STRIDE = 32
 COMM_ID_BYTES = 128
 MAX_PARAMS = 5
-ABI_VERSION = 300          # GCLM_VERSION of include/gclm.h this binding was written against
+ABI_VERSION = 400          # GCLM_VERSION of include/gclm.h this binding was written against
 INFO = {"stop_at": 0, "initial_up_cost": 1, "initial_latitude_cost": 2, "initial_cost": 3,
         "final_up_cost": 4, "final_latitude_cost": 5, "final_cost": 6, "roll_uncertainty": 7,
         "pitch_uncertainty": 8, "gravity_uncertainty": 9, "focal_uncertainty": 10,
@@ -87,6 +87,7 @@ _SIGNATURES = {
     "gclm_comm_create": (C.c_int, [C.POINTER(_P), _P, C.c_int, C.c_int, C.c_int]),
     "gclm_comm_destroy": (C.c_int, [_P]),
     "gclm_comm_last_error": (C.c_char_p, [_P]),
+    "gclm_comm_versions": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gclm_comm_all_gather": (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
     "gclm_comm_all_reduce_sum": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "gclm_comm_all_reduce_sum_i32": (C.c_int, [_P, _P, C.c_size_t, _P]),

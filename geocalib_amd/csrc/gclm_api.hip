@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "gclm_internal.h"
@@ -47,9 +48,10 @@ struct gclm_handle {
     int fused_mode = -1;            // gclm_set_fused_steps: -1 = built-in choice, 0 = never, 1 = whenever it is valid
     gclm_comm* stop_comm = nullptr; // gclm_set_stop_comm: the batch-global early stop spans the ranks of this communicator
     int paced_depth = 0;            // gclm_set_paced_launches: 0 = off, d = launch k waits for launch k-d's report
-    int* progress_host = nullptr;   // ... the host-mapped word the launches report to (owned), its device alias
-    int* progress_dev = nullptr;
-    int epoch = 0;                  // ... and the tag of the current solve in it
+    unsigned* progress_host = nullptr;   // ... the host-mapped word the launches report to (owned), its device alias
+    unsigned* progress_dev = nullptr;
+    unsigned epoch = 0;             // ... and the tag of the current solve in it
+    int paced_cooldown = 0;         // solves left to run UNPACED after a wait timed out (the queue was not ours)
     // optional timing of the sweep launches
     bool timing = false;
     std::vector<hipEvent_t> ev;
@@ -58,7 +60,7 @@ struct gclm_handle {
 
 namespace {
 
-std::string g_create_error;
+thread_local std::string g_create_error;
 
 int fail(gclm_handle* h, int code, const char* fmt, ...) {
     char buf[512];
@@ -204,7 +206,8 @@ bool use_fused(const gclm_handle* h, int B, const Geometry& g) {
 }
 
 int check_shapes(gclm_handle* h, const float* lat, int B, int H, int W) {
-    if (!lat) return fail(h, -3, "latitude_field is required (lm_optimizer.py:31 raises KeyError without it)");
+    // (an EMPTY batch has no fields: a zero-size device tensor's pointer is NULL -- run_solve's B == 0 branch)
+    if (!lat && B != 0) return fail(h, -3, "latitude_field is required (lm_optimizer.py:31 raises KeyError without it)");
     if (B < 0 || H <= 0 || W <= 0) return fail(h, -3, "bad shape B=%d H=%d W=%d", B, H, W);
     if (B > 65535) return fail(h, -3, "batch %d exceeds 65535 images per call (grid.y): split the batch", B);
     if ((size_t)H * W >= (size_t)1 << 30) return fail(h, -3, "image too large");
@@ -372,11 +375,11 @@ int gclm_set_paced_launches(gclm_handle* h, int depth) {
         GCLM_HIP(h, guard.status);
         void* p = nullptr;
         GCLM_HIP(h, hipHostMalloc(&p, 64, hipHostMallocMapped));
-        h->progress_host = static_cast<int*>(p);
+        h->progress_host = static_cast<unsigned*>(p);
         *h->progress_host = 0;
         void* d = nullptr;
         GCLM_HIP(h, hipHostGetDevicePointer(&d, p, 0));
-        h->progress_dev = static_cast<int*>(d);
+        h->progress_dev = static_cast<unsigned*>(d);
     }
     h->paced_depth = depth;
     return 0;
@@ -436,7 +439,8 @@ static int run_solve(gclm_handle* h, const float* d_up, const float* d_lat, cons
     c.B = B; c.H = H; c.W = W; c.nchunks = geo.nchunks;
     // trivial / heuristic initial estimate without `scales`: fx == fy at the start, and update_focal keeps the ratio
     // (camera.py:148) -- the final sweep may then run the cheaper log-focal instantiation (see finalize_kernel)
-    c.iso_final = (ia.cam == nullptr && ia.scales == nullptr && GCLM_ISO_FINAL) ? 1 : 0;
+    // (only where the sweep HAS a log-focal instantiation: a -DGCLM_LOGF=0 build of gclm_pass.hip takes the general column)
+    c.iso_final = (ia.cam == nullptr && ia.scales == nullptr && GCLM_ISO_FINAL && sweep_has_log_focal()) ? 1 : 0;
     if (int rc = setup_groups(h, B)) return rc;
     if (int rc = ensure_workspace(h, B, geo.nchunks, c.n_groups)) return rc;
     h->sh.active = false;
@@ -450,25 +454,36 @@ static int run_solve(gclm_handle* h, const float* d_up, const float* d_lat, cons
         // still costs its turn on the queue (2.3 us x 21 of a default-conf solve).  Launch k is therefore only issued
         // once launch k - depth has reported (a word in host-mapped memory), and none once the stop is reported.  What
         // the host sees only decides how many launches it issues: the device-side skip stays in force, so a late or
-        // missing report costs time, never correctness; the wait gives up after 20 ms.
-        const bool paced = h->paced_depth > 0 && es && B == 1 && h->progress_host;
+        // missing report costs time, never correctness; the wait is bounded (kPacedPatienceUs, then a cool-down).
+        bool paced = h->paced_depth > 0 && es && B == 1 && h->progress_host;
+        if (paced && h->paced_cooldown > 0) { --h->paced_cooldown; paced = false; }
         if (paced) h->epoch = (h->epoch + 1) & kPacedEpochMask;
         bool stop_seen = false, pace = paced;
         auto reported = [&](int launch) {          // has `launch` (or a later one) of THIS solve reported?  sets stop_seen
-            const int v = __atomic_load_n(h->progress_host, __ATOMIC_ACQUIRE);
+            const unsigned v = __atomic_load_n(h->progress_host, __ATOMIC_ACQUIRE);
             if (((v >> kPacedEpochShift) & kPacedEpochMask) != h->epoch) return false;
             if (v & kPacedStopBit) stop_seen = true;
-            return stop_seen || (v & 0xffff) >= launch + 1;
+            return stop_seen || (v & 0xffffu) >= (unsigned)(launch + 1);
         };
         for (int step = 0; step <= h->cfg.num_steps; ++step) {
             const bool fin = step == h->cfg.num_steps;
             if (pace && !fin && step >= h->paced_depth) {
+                // A launch of this solve reports within a few microseconds of the previous one when the queue is ours.
+                // Spin briefly (the common case), then yield the core between polls; give up after kPacedPatienceUs.
+                // A queue backed up by other streams (a serving loop overlapping the CNN with the LM) trips that: the rest
+                // of THIS solve is issued unpaced, and the handle stops pacing for the next kPacedCooldown solves instead
+                // of burning the patience on every call.
                 const auto t0 = std::chrono::steady_clock::now();
-                for (unsigned spin = 0; !reported(step - h->paced_depth); ++spin)
-                    if ((spin & 0x3ff) == 0x3ff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
-                        pace = false;              // the device is busy elsewhere: issue the rest unpaced
+                for (unsigned spin = 0; !reported(step - h->paced_depth); ++spin) {
+                    if (spin < 256) continue;
+                    std::this_thread::yield();
+                    if ((spin & 0xf) == 0 &&
+                        std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(kPacedPatienceUs)) {
+                        pace = false;
+                        h->paced_cooldown = kPacedCooldown;
                         break;
                     }
+                }
             }
             if (stop_seen && !fin) continue;       // the final launch finds the stop in the counters, as it always does
             SweepArgs a = sweep_args(h, d_up, d_lat, d_up_conf, d_lat_conf, c.pb[0], geo, !fin, 0);
@@ -525,8 +540,9 @@ int gclm_calibrate(gclm_handle* h, const float* d_up, const float* d_lat, const 
                    int prior_dist_cols, float* d_cam_out, float* d_grav_out, float* d_info_out, void* stream) {
     if (!h) return -1;
     if (d_prior_dist && (prior_dist_cols < 1 || prior_dist_cols > 2)) return fail(h, -3, "gclm_calibrate: prior_dist_cols must be 1 or 2");
-    // the free-parameter flags must agree with the priors (setup_optimization_and_priors, :204-221)
-    if ((d_prior_focal != nullptr) == (h->cfg.estimate_focal != 0) || (d_prior_gravity != nullptr) == (h->cfg.estimate_gravity != 0))
+    // the free-parameter flags must agree with the priors (setup_optimization_and_priors, :204-221); an empty batch has
+    // no prior rows either (NULL), and only takes part in the stop collectives
+    if (B != 0 && ((d_prior_focal != nullptr) == (h->cfg.estimate_focal != 0) || (d_prior_gravity != nullptr) == (h->cfg.estimate_gravity != 0)))
         return fail(h, -2, "gclm_calibrate: estimate_focal / estimate_gravity disagree with the priors passed");
     InitArgs ia{};
     ia.scales = d_scales;
@@ -536,7 +552,7 @@ int gclm_calibrate(gclm_handle* h, const float* d_up, const float* d_lat, const 
     ia.prior_dist_cols = prior_dist_cols;
     ia.up = d_up;
     ia.lat = d_lat;
-    if (h->cfg.heuristic_init && !d_up) return fail(h, -3, "gclm_calibrate: heuristic_init needs the up field");
+    if (h->cfg.heuristic_init && !d_up && B != 0) return fail(h, -3, "gclm_calibrate: heuristic_init needs the up field");
     return run_solve(h, d_up, d_lat, d_up_conf, d_lat_conf, B, H, W, ia, d_cam_out, d_grav_out, d_info_out, stream);
 }
 

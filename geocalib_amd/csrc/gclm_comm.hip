@@ -87,6 +87,7 @@ int gclm_comm_destroy(gclm_comm* c) {
 const char* gclm_comm_last_error(const gclm_comm* c) { return c ? c->err.c_str() : g_comm_error.c_str(); }
 
 int gclm_comm_all_gather(gclm_comm* c, const float* d_send, float* d_recv, size_t count_per_rank, void* stream) {
+    if (c && count_per_rank == 0) return 0;        // every rank passes the same count: nothing to exchange anywhere
     if (!c || !d_send || !d_recv) return cfail(c, -1, "gclm_comm_all_gather", "null argument");
     ncclResult_t r = ncclAllGather(d_send, d_recv, count_per_rank, ncclFloat, c->comm, static_cast<hipStream_t>(stream));
     return r == ncclSuccess ? 0 : cfail(c, -20, "ncclAllGather", ncclGetErrorString(r));

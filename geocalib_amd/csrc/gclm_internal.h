@@ -141,12 +141,15 @@ struct FusedArgs {
     int step;                   // the launch sweeps theta_step after applying update step-1 (final launch: num_steps)
     int is_final;               // the uncertainty sweep: (roll, pitch, focal) block, takes over prep_final_kernel
     const float* partials_in;   // the partial records of the previous launch (the other half of the double buffer)
-    int* progress;              // paced launches (gclm_set_paced_launches): host-mapped word image 0 reports to, or null
-    int epoch;                  // ... and the tag of this solve in it (stale words of earlier solves are ignored)
+    unsigned* progress;         // paced launches (gclm_set_paced_launches): host-mapped word image 0 reports to, or null
+    unsigned epoch;             // ... and the tag of this solve in it (stale words of earlier solves are ignored)
 };
 // the word a paced launch publishes: [31:20] epoch of the solve, bit 16 "the early stop fired here", [15:0] step + 1
-constexpr int kPacedStopBit = 1 << 16;
-constexpr int kPacedEpochShift = 20, kPacedEpochMask = 0xfff;
+constexpr unsigned kPacedStopBit = 1u << 16;
+constexpr unsigned kPacedEpochShift = 20, kPacedEpochMask = 0xfffu;
+constexpr int kPacedPatienceUs = 2000;    // host wait for one report before the rest of the solve is issued unpaced ...
+constexpr int kPacedCooldown = 64;        // ... and solves of that handle that then do not pace at all
+bool sweep_has_log_focal();               // gclm_pass.hip: false in a -DGCLM_LOGF=0 measurement build
 hipError_t launch_fused_step(int camera_model, const SweepArgs& a, const FusedArgs& f, hipStream_t s);
 hipError_t launch_init(const SolveCtx& c, const InitArgs& ia, hipStream_t s);
 hipError_t launch_update(const SolveCtx& c, int step, hipStream_t s);

@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(kBlock) void fused_step_kernel(const SweepArgs a, c
             // paced launches: tell the host how far image 0 has come and whether the stop fired, so that it stops issuing
             // launches nobody needs (a system-scope store into host-mapped memory; nothing else is ordered by it)
             if (f.progress && b == 0)
-                __hip_atomic_store(f.progress, (f.epoch << kPacedEpochShift) | (stop_now ? kPacedStopBit : 0) | (step + 1),
+                __hip_atomic_store(f.progress, (f.epoch << kPacedEpochShift) | (stop_now ? kPacedStopBit : 0u) | (unsigned)(step + 1),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (commit) {
                 c.state[step & 1][b] = fin;
@@ -1193,6 +1193,8 @@ hipError_t launch_sweep(int camera_model, const SweepArgs& a, hipStream_t s) {
         default: return hipErrorInvalidValue;
     }
 }
+
+bool sweep_has_log_focal() { return GCLM_LOGF != 0; }
 
 hipError_t launch_fused_step(int camera_model, const SweepArgs& a, const FusedArgs& f, hipStream_t s) {
     if (a.B <= 0) return hipSuccess;

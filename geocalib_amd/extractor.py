@@ -37,14 +37,18 @@ def default_preprocess(img: torch.Tensor, resize: int = 320, edge_divisible_by: 
 class GeoCalib(nn.Module):
     """Single-image (or shared-intrinsics multi-image) calibration front-end."""
 
-    def __init__(self, field_model: Callable, preprocess: Callable = default_preprocess, **optimizer_options):
+    def __init__(self, field_model: Callable, preprocess: Callable = default_preprocess, paced_launches: int = 3,
+                 **optimizer_options):
+        """`paced_launches` (no reference counterpart; include/gclm.h: gclm_set_paced_launches): calibrate() reads the camera
+        on the host right after the solve (_post_process), so a single-image solve may pace its launches against the
+        device's early stop -- the call then blocks for about the LM loop (~0.15 ms) instead of returning at once, and the
+        result is there ~20 % earlier.  Pass 0 in a serving loop that keeps other streams busy while it calibrates: the
+        wait is bounded (2 ms, then the handle stops pacing for its next 64 solves), but it is a wait."""
         super().__init__()
         self.field_model = field_model
         self.preprocess = preprocess
         self.optimizer = LMOptimizer({**optimizer_options})
-        # calibrate() reads the camera on the host right after the solve (_post_process), so nothing is lost by letting a
-        # single-image solve pace its launches against the device's early stop (LMOptimizer.paced_launches)
-        self.optimizer.paced_launches = 3
+        self.optimizer.paced_launches = int(paced_launches)
 
     def _post_process(self, camera: BaseCamera, img_data: Dict[str, torch.Tensor], out: Dict[str, torch.Tensor]):
         """Undo scaling / cropping and bring the fields back to the input resolution."""

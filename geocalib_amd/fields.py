@@ -67,7 +67,7 @@ def upsample_fields(t: torch.Tensor, size) -> torch.Tensor:
     return dst
 
 
-def fastest_placement(allocate, solve, tries: int = 3):
+def fastest_placement(allocate, solve, tries: int = 3, keep_first: bool = False):
     """Pick, out of `tries` allocations of the same field buffers, the one the sweep streams fastest.
 
     Where a batch of fields lands in PHYSICAL memory moves the memory-bound sweep by up to 8 % (928 ...
@@ -79,9 +79,15 @@ def fastest_placement(allocate, solve, tries: int = 3):
                       different pages);   solve(fields) -> anything (one calibration of the candidate, e.g. an LMOptimizer)
 
     Every candidate is solved twice (warm-up, then timed with HIP events on the current stream); returns
-    (fields_of_the_fastest, [milliseconds of every candidate]).  The others are dropped."""
+    (fields_of_the_fastest, [milliseconds of every candidate]).  The others are dropped.  `keep_first`: a third value,
+    the FIRST candidate's fields (what a caller who allocates once gets) -- measurement rigs report both.
+
+    Round 4 tried to control the placement instead of choosing it (HIP virtual-memory management: one physical handle per
+    batch / per tensor / per 2 MiB .. 1 GiB chunk, 1 GiB-aligned tensors): same spread, same discrete levels
+    (profiles/r04_vmm_placement.log) -- choosing among allocations stays the only handle a caller has."""
     if tries <= 1:
-        return allocate(), []
+        f = allocate()
+        return (f, [], f) if keep_first else (f, [])
     cands, times = [], []
     for _ in range(tries):
         f = allocate()
@@ -94,4 +100,4 @@ def fastest_placement(allocate, solve, tries: int = 3):
         cands.append(f)
         times.append(e0.elapsed_time(e1))
     best = min(range(tries), key=times.__getitem__)
-    return cands[best], times
+    return (cands[best], times, cands[0]) if keep_first else (cands[best], times)

@@ -432,7 +432,7 @@ class LMOptimizer(nn.Module):
         grav = torch.empty((B, 3), dtype=torch.float32, device=device)
         info = torch.empty((B, _lib.INFO_STRIDE), dtype=torch.float32, device=device)
         P = self._ptr           # (the library switches to the handle's device itself: no torch.cuda.device() context)
-        n_over = self._overlap_parts(B)
+        n_over = self._overlap_parts(B, H, W)
         if n_over > 1:
             self._calibrate_overlapped(n_over, device, (up, lat, upc, latc), (B, H, W), scales, (pf, pg, pd), nd, (cam, grav, info))
         else:
@@ -446,17 +446,27 @@ class LMOptimizer(nn.Module):
     # Host-side knob without a reference counterpart.  n > 1: a large batch of INDEPENDENT images with a fixed step count
     # is solved as n contiguous parts on n side streams (forked from / joined to the caller's stream with events), so that
     # one part's per-step update launch and kernel boundaries run under another part's sweep -- the 1.5 % between the
-    # sweep's and the whole job's roofline fraction (pinhole 50.4 -> 51.2 k images/s at B = 1024,
-    # simple_radial +-0).  Images are independent, so the results are those of the single call up to the summation order
-    # of an image's partial records -- bit-identical whenever the parts are cut like the whole batch (the cut depends on
-    # the batch size only below 2048 workgroups per call: 137 images of 640x480).  Ignored where it does not apply:
-    # early_stop (one decision over the whole batch), shared intrinsics, fewer than `_OVERLAP_MIN_IMAGES` images per part.
-    overlap_streams = 1
+    # sweep's and the whole job's roofline fraction (pinhole +2.3 % at B = 1024, simple_radial +-0).
+    # Images are independent, so the results are those of the single call up to the summation order of an image's partial
+    # records -- bit-identical whenever the parts are cut like the whole batch (the cut depends on the batch size only
+    # below 2048 workgroups per call: 137 images of 640x480).
+    #   None (default): the library decides -- 2 parts when every part keeps >= `_OVERLAP_MIN_IMAGES` images AND is far
+    #                   inside the regime where the cut does not depend on the batch size (`_OVERLAP_AUTO_PIXELS` pixels per
+    #                   part: 410 images of 640x480), i.e. only where the result is the single call's bit for bit; 1 otherwise.
+    #   1: never (measurement rigs that time single launches: overlapping launches have no separable durations).
+    #   n > 1: n parts wherever every part keeps `_OVERLAP_MIN_IMAGES` images.
+    # Ignored where it does not apply: early_stop (one decision over the whole batch), shared intrinsics.
+    overlap_streams = None
     _OVERLAP_MIN_IMAGES = 256
+    _OVERLAP_AUTO_PIXELS = 3 * 2048 * 20480      # 3 x (2048 workgroups x 20 480 pixels per workgroup at 20 iterations)
 
-    def _overlap_parts(self, B: int) -> int:
+    def _overlap_parts(self, B: int, H: int = 480, W: int = 640) -> int:
+        if self.conf.early_stop or self.shared_intrinsics:
+            return 1
+        if self.overlap_streams is None:
+            return 2 if (B // 2 >= self._OVERLAP_MIN_IMAGES and (B // 2) * H * W >= self._OVERLAP_AUTO_PIXELS) else 1
         n = int(self.overlap_streams)
-        if n <= 1 or self.conf.early_stop or self.shared_intrinsics:
+        if n <= 1:
             return 1
         return max(1, min(n, B // self._OVERLAP_MIN_IMAGES))
 

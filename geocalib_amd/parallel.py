@@ -235,7 +235,15 @@ def calibrate_sharded(opt: LMOptimizer, local_data: Dict[str, torch.Tensor], n_t
     forced = os.environ.get("GCLM_FORCE_COLLECTIVES") == "1"
     multi = comm is not None and (comm.nranks > 1 or forced) or collectives_on(group)
     stop_handle = None
-    if opt.conf.early_stop and multi:
+    if not multi:
+        return opt(local_data)            # one rank, no forced collective: nothing to pack, nothing to exchange
+    if opt.conf.early_stop:
+        if next(iter(local_data.values())).shape[0] > opt._MAX_CALL:
+            # a shard beyond one C call is solved in slices (LMOptimizer._calibrate_chunked), each with its own sequence of
+            # stop all-reduces: ranks with different slice counts would issue mismatched collectives, and the stop would
+            # be per slice, not the batch's
+            raise ValueError(f"calibrate_sharded with early_stop=True is limited to {opt._MAX_CALL} images per rank "
+                             "(one C call, one sequence of stop collectives): use early_stop=False or more ranks")
         # The reference's early stop is ONE decision over the whole batch (lm_optimizer.py:90-92, 619); every rank taking
         # it over its own shard would make the gathered result depend on the world size.  With an
         # RCCL communicator the per-step "cost still moved" counters are summed over the ranks on the solve's stream
@@ -254,7 +262,7 @@ def calibrate_sharded(opt: LMOptimizer, local_data: Dict[str, torch.Tensor], n_t
         stop_handle = opt._handle(next(iter(local_data.values())).device)
         _lib.check(_lib.load().gclm_set_stop_comm(stop_handle.ptr, stop_comm._ptr), stop_handle.ptr, "gclm_set_stop_comm")
     try:
-        out = opt(local_data)
+        opt(local_data)
     finally:
         if stop_handle is not None:
             _lib.load().gclm_set_stop_comm(stop_handle.ptr, None)
@@ -265,10 +273,8 @@ def calibrate_sharded(opt: LMOptimizer, local_data: Dict[str, torch.Tensor], n_t
         gathered = (timer(lambda: comm.all_gather(rows, recv), rows.device) if timer is not None
                     else comm.all_gather(rows, recv))
         return infos_from_rows(opt, gathered, "up_field" in local_data)
-    if collectives_on(group):
-        rows = all_gather_rows(rows, n_total, group, plan, timer)
-        return infos_from_rows(opt, rows, "up_field" in local_data)
-    return out
+    rows = all_gather_rows(rows, n_total, group, plan, timer)
+    return infos_from_rows(opt, rows, "up_field" in local_data)
 
 
 class SharedIntrinsicsSplit:

@@ -33,9 +33,11 @@ extern "C" {
 
 /* ABI version: bumped whenever struct gclm_config or the export list changes (100 = round 1/2, 300 = round 3:
  * struct_size / abi_version / device moved into gclm_config, gclm_create lost its third argument, new entry points
- * gclm_set_sweep_iters, gclm_set_fused_steps, gclm_set_paced_launches, gclm_set_stop_comm, gclm_comm_all_reduce_sum_i32, gclm_abi_config_size).  gclm_create refuses a gclm_config whose first two fields do not
+ * gclm_set_sweep_iters, gclm_set_fused_steps, gclm_set_paced_launches, gclm_set_stop_comm, gclm_comm_all_reduce_sum_i32,
+ * gclm_abi_config_size; 400 = round 4: gclm_comm_versions added, the NULL-handle error strings became thread-local, an
+ * empty batch (B = 0, NULL fields) is accepted by gclm_solve / gclm_calibrate).  gclm_create refuses a gclm_config whose first two fields do not
  * carry the library's own sizeof(gclm_config) and GCLM_VERSION, with a message naming both sides. */
-#define GCLM_VERSION 300
+#define GCLM_VERSION 400
 
 /* camera_models of geocalib/camera.py:945-950 */
 enum gclm_camera_model {
@@ -122,7 +124,8 @@ int gclm_configure(gclm_handle* h, const gclm_config* cfg);
 
 int gclm_destroy(gclm_handle* h);
 
-/* Message of the last failing call on this handle (or of the last failing gclm_create if h == NULL). */
+/* Message of the last failing call on this handle; h == NULL: of the last failing gclm_create of the CALLING THREAD
+ * (thread-local storage: two threads creating handles do not see each other's message). */
 const char* gclm_last_error(const gclm_handle* h);
 
 /* Bytes of device scratch the handle holds (grows on demand in gclm_solve, never per call after warm-up). */
@@ -284,7 +287,13 @@ typedef struct gclm_comm gclm_comm;
 int gclm_comm_unique_id(void* id_out /* GCLM_COMM_ID_BYTES */);
 int gclm_comm_create(gclm_comm** out, const void* unique_id, int nranks, int rank, int device);
 int gclm_comm_destroy(gclm_comm* c);
+/* Message of the last failing call on this communicator; c == NULL: of the last failing gclm_comm_unique_id /
+ * gclm_comm_create of the CALLING THREAD (thread-local, as gclm_last_error(NULL)). */
 const char* gclm_comm_last_error(const gclm_comm* c);
+/* NCCL_VERSION_CODE of the rccl.h this library was compiled against and ncclGetVersion() of the librccl the dynamic
+ * loader actually bound (a process that loaded another librccl.so.1 first -- torch ships its own -- keeps that one).
+ * gclm_comm_create refuses (-21) a run-time library of another MAJOR version. */
+int gclm_comm_versions(int* compiled, int* runtime);
 int gclm_comm_all_gather(gclm_comm* c, const float* d_send, float* d_recv, size_t count_per_rank, void* stream);
 int gclm_comm_all_reduce_sum(gclm_comm* c, float* d_buf, size_t count, void* stream);
 int gclm_comm_all_reduce_sum_i32(gclm_comm* c, int32_t* d_buf, size_t count, void* stream);
@@ -319,7 +328,9 @@ int gclm_set_fused_steps(gclm_handle* h, int mode);
  * thread for about the duration of the LM loop (the results are still produced asynchronously on the stream).  For
  * callers that read the result right away (the reference's GeoCalib.calibrate does: extractor.py:51-69).  0 (default)
  * = off: every launch is issued at once, the call returns immediately.  Ignored where it cannot help (more than one
- * image, early_stop = 0, the two-launch path).  Results do not depend on it.  depth in [0, 16]; 3 is a good value. */
+ * image, early_stop = 0, the two-launch path).  Results do not depend on it.  depth in [0, 16]; 3 is a good value.
+ * The host wait spins briefly, then yields between polls; if a report does not arrive within 2 ms (the queue is shared
+ * with other streams) the rest of that solve is issued unpaced and the handle does not pace its next 64 solves. */
 int gclm_set_paced_launches(gclm_handle* h, int depth);
 
 /* Timing helper: when enabled, every sweep launch is bracketed by HIP events on the solve's stream;

@@ -76,6 +76,11 @@ def _early_stop_worker(rank, world):
     from geocalib_amd.parallel import calibrate_sharded
     with pytest.raises(ValueError, match="early_stop=False"):
         calibrate_sharded(LMOptimizer({"camera_model": "pinhole"}), {"latitude_field": torch.zeros(4, 1, 8, 8)}, 8)
+    # a shard beyond one C call would be solved in slices, each with its own sequence of stop collectives: ranks with
+    # different slice counts would deadlock and the stop would be per slice -- refused up front as well
+    big = torch.zeros(1, 1, 2, 2).expand(LMOptimizer._MAX_CALL + 1, 1, 2, 2)             # a view: no memory behind it
+    with pytest.raises(ValueError, match="65535 images per rank"):
+        calibrate_sharded(LMOptimizer({"camera_model": "pinhole"}), {"latitude_field": big}, 2 * big.shape[0])
 
 
 def test_calibrate_sharded_refuses_early_stop_world2():

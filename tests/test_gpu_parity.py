@@ -711,6 +711,24 @@ def test_sharded_early_stop_through_the_stop_communicator(dev):
     assert 1 < whole["stop_at"][0] < 30
     h = opt._handle(dev)
     assert lib.gclm_set_stop_comm(h.ptr, None) == 0                     # and it was unset again after the call
+    # (1b) an EMPTY local shard (n_total < world, or an uneven split) must still take part in the per-step collectives of
+    # its peers instead of failing the shape checks (a zero-size tensor's pointer is NULL): through the Python
+    # wrapper, with the stop communicator set, the call goes through and returns empty results
+    _os.environ["GCLM_FORCE_COLLECTIVES"] = "1"
+    try:
+        none = calibrate_sharded(LMOptimizer(conf).eval(), {k: v[:0] for k, v in data.items()}, 0, comm=comm)
+    finally:
+        _os.environ.pop("GCLM_FORCE_COLLECTIVES", None)
+    torch.cuda.synchronize()
+    assert none["camera"]._data.shape == (0, 8) and none["stop_at"].shape == (0,)
+    # ... and the C entry point itself: B = 0 with NULL fields and outputs is not an error, with or without a stop communicator
+    for c in (None, comm._ptr):
+        assert lib.gclm_set_stop_comm(h.ptr, c) == 0
+        assert lib.gclm_calibrate(h.ptr, None, None, None, None, 0, 96, 128, None, None, None, None, 0, None, None, None,
+                                  torch.cuda.current_stream(dev).cuda_stream) == 0, _lib.last_error(h.ptr)
+    assert lib.gclm_set_stop_comm(h.ptr, None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(to_np(opt(data))["camera"], whole["camera"])   # the handle is as good as before
     # (2) shards on their own: each stops when ITS images have converged -- generally not where the batch stops
     lo, hi = run_dev(conf, {k: v[:6] for k, v in data.items()}), run_dev(conf, {k: v[6:] for k, v in data.items()})
     assert max(lo["stop_at"][0], hi["stop_at"][0]) == whole["stop_at"][0]        # the slower shard IS the batch's stop
@@ -1039,6 +1057,69 @@ def test_bench_multi_rank_path_on_one_gpu(dev, extra):
     assert len(out["ms_per_step_repeats"]) == out["repeats"] == 3
 
 
+@pytest.mark.parametrize("extra", [[], ["--shared-group", "16"]])
+def test_bench_starts_its_own_ranks(dev, extra):
+    """`python bench.py --gpus 2` WITHOUT a launcher (how the driver records its single-GPU command): the
+    script re-executes itself under torch.distributed.run, rank 0 prints exactly ONE line on stdout, and that line
+    describes both ranks.  (gloo: the two ranks share this box's one GPU, which RCCL refuses.)"""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--batch", "64", "--steps", "2",
+           "--warmup", "1", "--cpu-sample", "0"] + extra
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 128 and out["value"] > 0
+    mg = out["multi_gpu"]
+    assert mg["ranks_seen"] == 2 and len(mg["per_rank_ms"]) == 2 and "bench.py itself" in mg["launched_by"]
+    assert mg["rccl"]["compiled"] >= 22000 and mg["rccl"]["runtime"] >= 22000
+    # with the real backend two ranks need two GPUs: on a one-GPU box the answer is ONE JSON line with an error, not a trace
+    if torch.cuda.device_count() < 2:
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "64"], capture_output=True,
+                             text=True, timeout=300, cwd=ROOT, env=env)
+        lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+        assert res.returncode != 0 and len(lines) == 1
+        err = json.loads(lines[0])
+        assert err["value"] is None and "only 1 HIP device" in err["error"] and err["n_gpus"] == 2
+
+
+def test_bench_single_gpu_line_carries_secondary_overlap_and_first_allocation(dev):
+    """The N=1 line of record (small shapes here): `secondary` = configs[3] (simple_radial) and configs[4]'s shape
+    (shared-16) with their own roofline blocks, `overlap` = the same batch as two halves on two streams (bit-identical),
+    `placement` with the chosen allocation and -- when another one was chosen -- the first allocation's own measurement,
+    `cpu_baseline` from this box (the port; the reference checkout does not exist on the GPU box)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "512", "--height", "96", "--width", "128", "--steps", "2",
+           "--warmup", "1", "--cpu-sample", "4", "--placement-tries", "3"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["streams"] == 1
+    sec = out["secondary"]
+    assert set(sec) == {"simple_radial_B512", "shared16_pinhole"}
+    for rec in sec.values():
+        assert rec["value"] > 0 and rec["steps"] == 5 and rec["roofline"]["launches_timed"] == 5 * 21
+        assert 0 < rec["roofline"]["frac"] < 1 and rec["check"]["median_focal_rel_err_vs_gt"] < 5e-3
+    assert sec["shared16_pinhole"]["unit"] == "frames/sec" and "configs[4]" in sec["shared16_pinhole"]["workload"]
+    ov = out["overlap"]
+    assert ov["streams"] == 2 and ov["value"] > 0 and ov["bit_identical"] is True
+    pl = out["placement"]
+    assert pl["tries"] == 3 and len(pl["solve_ms"]) == 3 and pl["chosen"] == pl["solve_ms"].index(min(pl["solve_ms"]))
+    assert ("first_allocation" in pl) == (pl["chosen"] != 0)
+    cb = out["cpu_baseline"]
+    assert cb["value"] > 0 and cb["kind"] in ("port", "reference") and cb["reference_on_this_box"] == (cb["kind"] == "reference")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("model", ALL_MODELS)
 @pytest.mark.parametrize("tag", ["loop", "rpf"])
@@ -1135,7 +1216,7 @@ def test_jacobian_fields_match_autograd_of_the_forward_model(dev, model):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--shared-group", "16"]])
+@pytest.mark.parametrize("extra", [[], ["--shared-group", "16"], ["--comm", "rccl"], ["--shared-group", "16", "--comm", "rccl"]])
 def test_bench_collectives_through_rccl_with_one_rank(dev, extra):
     """The N>1 code path of bench.py with the REAL backend: torch.distributed "nccl" (= RCCL) process group,
     barrier, max-reduce of the timing, the result all-gather / the per-step all-reduce of the Schur partials --
@@ -1158,6 +1239,10 @@ def test_bench_collectives_through_rccl_with_one_rank(dev, extra):
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["global_batch"] == 64
     assert out["multi_gpu"]["ranks_seen"] == 1 and out["multi_gpu"]["backend"] == "nccl"
     assert out["multi_gpu"]["collective_ms"] > 0          # the collective really went through RCCL on the stream
+    v = out["multi_gpu"]["rccl"]                          # which librccl this process bound vs the header of the build
+    assert v["compiled"] == 22707 and v["runtime"] // 10000 == 2
+    if "--comm" in extra:
+        assert "gclm_comm_" in out["multi_gpu"]["comm"]
 
 
 @pytest.mark.gpu
@@ -1608,3 +1693,9 @@ def test_overlap_streams_equals_the_single_call(dev, model):
     small = LMOptimizer({"camera_model": model, "early_stop": False})
     small.overlap_streams = 2
     assert small._overlap_parts(300) == 1 and small._overlap_parts(512) == 2
+    # the default (None): the library decides -- two parts only far inside the regime where a part is cut like the batch
+    auto = LMOptimizer({"camera_model": model, "early_stop": False})
+    assert auto.overlap_streams is None
+    assert auto._overlap_parts(1024, 480, 640) == 2 and auto._overlap_parts(820, 480, 640) == 2
+    assert auto._overlap_parts(513, 480, 640) == 1 and auto._overlap_parts(4096, 96, 128) == 1
+    assert LMOptimizer({"camera_model": model})._overlap_parts(1024, 480, 640) == 1            # early stop
