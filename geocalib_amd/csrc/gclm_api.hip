@@ -234,7 +234,7 @@ namespace gclm {
 // then for the smallest tile (640 px: 160 units, rpi = 2, 320 lanes = 5 waves, no idle lane).  Wider rows are cut
 // into strips of a multiple of 64 units, one row per iteration.  Every wave of a tile is a job; a workgroup is four
 // consecutive jobs of an image.
-Geometry plan_geometry(int B, int H, int W, bool aligned16, int sweep_iters) {
+Geometry plan_geometry(int B, int H, int W, bool aligned16, int sweep_iters, int camera_model) {
     Geometry g;
     g.vec = (aligned16 && (W % 4 == 0)) ? 4 : 1;
     g.wu = W / g.vec;
@@ -264,7 +264,12 @@ Geometry plan_geometry(int B, int H, int W, bool aligned16, int sweep_iters) {
     }
     // ~20 loop iterations per lane amortise the 16-value workgroup reduction; fewer when the batch alone cannot
     // fill 256 CUs x 4+ workgroups.
-    int iters = (sweep_iters >= 1 && sweep_iters <= 4096) ? sweep_iters : 20;   // gclm_set_sweep_iters (tuning / tests)
+    // The distortion models are VALU-bound: their per-workgroup prologue / epilogue is worth amortising over
+    // 30 iterations where the image divides into whole blocks of that many rows (640x480: 8 blocks of 60 rows; same-allocation
+    // A/B profiles/r04_variant_huber_clamp.log: simple_radial -0.3 %, radial -1.2 %, simple_divisional -0.7 %, pinhole +0.4 %).
+    int builtin = 20;
+    if (camera_model != GCLM_PINHOLE && H % (g.rpi * 30) == 0) builtin = 30;
+    int iters = (sweep_iters >= 1 && sweep_iters <= 4096) ? sweep_iters : builtin;   // gclm_set_sweep_iters (tuning / tests)
     auto jobs = [&](int it) { return g.nstrips * g.wpt * ((H + g.rpi * it - 1) / (g.rpi * it)); };
     auto chunks = [&](int it) { return (jobs(it) + kBlock / 64 - 1) / (kBlock / 64); };
     while (iters > 2 && (long long)B * chunks(iters) < 2048) iters = iters > 5 ? iters / 2 : iters - 1;
@@ -433,7 +438,7 @@ static int run_solve(gclm_handle* h, const float* d_up, const float* d_lat, cons
     DeviceGuard guard(h->device);
     GCLM_HIP(h, guard.status);
     const bool al = is_aligned16(d_up) && is_aligned16(d_lat) && is_aligned16(d_up_conf) && is_aligned16(d_lat_conf);
-    const Geometry geo = plan_geometry(B, H, W, al, h->sweep_iters);
+    const Geometry geo = plan_geometry(B, H, W, al, h->sweep_iters, h->cfg.camera_model);
     SolveCtx& c = h->ctx;
     c.cfg = h->cfg;
     c.B = B; c.H = H; c.W = W; c.nchunks = geo.nchunks;
@@ -567,7 +572,7 @@ int gclm_system(gclm_handle* h, const float* d_up, const float* d_lat, const flo
     DeviceGuard guard(h->device);
     GCLM_HIP(h, guard.status);
     const bool al = is_aligned16(d_up) && is_aligned16(d_lat) && is_aligned16(d_up_conf) && is_aligned16(d_lat_conf);
-    const Geometry geo = plan_geometry(B, H, W, al, h->sweep_iters);
+    const Geometry geo = plan_geometry(B, H, W, al, h->sweep_iters, h->cfg.camera_model);
     SolveCtx& c = h->ctx;
     c.cfg = h->cfg;
     c.B = B; c.H = H; c.W = W; c.nchunks = geo.nchunks;
@@ -594,7 +599,7 @@ int gclm_shared_begin(gclm_handle* h, const float* d_up, const float* d_lat, con
     GCLM_HIP(h, guard.status);
     const bool al = is_aligned16(d_up) && is_aligned16(d_lat) && is_aligned16(d_up_conf) && is_aligned16(d_lat_conf);
     const int Bp = B_local > 0 ? B_local : 1;
-    h->sh.geo = plan_geometry(Bp, H, W, al, h->sweep_iters);
+    h->sh.geo = plan_geometry(Bp, H, W, al, h->sweep_iters, h->cfg.camera_model);
     SolveCtx& c = h->ctx;
     c.cfg = h->cfg;
     c.B = B_local; c.H = H; c.W = W; c.nchunks = h->sh.geo.nchunks;

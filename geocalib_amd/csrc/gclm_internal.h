@@ -93,7 +93,7 @@ struct Geometry {          // how a sweep is cut into blocks (column-stationary 
     int vec, nchunks;
     int wu, cu, nstrips, rpi, rows_per_block, wpt, jobs;
 };
-Geometry plan_geometry(int B, int H, int W, bool aligned16, int sweep_iters = 0);
+Geometry plan_geometry(int B, int H, int W, bool aligned16, int sweep_iters = 0, int camera_model = 0);
 
 // gclm_pass.hip
 hipError_t launch_gradient_hessian(const float* d_J, const float* d_r, const float* d_w, int B, int N, int R, int P,

@@ -84,6 +84,15 @@
 #ifndef GCLM_NT_LOADS
 #define GCLM_NT_LOADS 1
 #endif
+#ifndef GCLM_RAY_FACTORED
+#define GCLM_RAY_FACTORED 1         // A/B switch: 0 = (e/n)(x_xy.uv) + x_z/n form of the latitude dot products (rounds 1-3)
+#endif
+#ifndef GCLM_HUBER_CLAMP
+#define GCLM_HUBER_CLAMP 1          // A/B switch: 0 = min(1, rsq) as a separate v_min_f32 (rounds 1-3)
+#endif
+#ifndef GCLM_EPS_FMA
+#define GCLM_EPS_FMA 1              // A/B switch: 0 = max(|q|^2, 1e-24) as a separate v_max_f32 (rounds 1-3)
+#endif
 #ifndef GCLM_DIV_GUARD_ALWAYS
 #define GCLM_DIV_GUARD_ALWAYS 0     // A/B switch: 1 = simple_divisional always runs the guarded body (round-2 behaviour)
 #endif
@@ -119,6 +128,17 @@ __device__ __forceinline__ f2 vclamp(f2 a, float lo, float hi) {
 // min(a, 1)
 __device__ __forceinline__ float vmin1(float a) { return fminf(a, 1.0f); }
 __device__ __forceinline__ f2 vmin1(f2 a) { return f2{fminf(a.x, 1.0f), fminf(a.y, 1.0f)}; }
+// min(1, 1/sqrt(y)) for y >= 0 in ONE instruction: v_rsq_f32 with the VOP3 clamp bit (the result is clamped to [0, 1];
+// rsq >= 0, rsq(0) = +inf -> 1).  Same bits as v_rsq_f32 + v_min_f32 for every y that is not NaN.
+__device__ __forceinline__ float vrsq_min1(float y) {
+#if GCLM_HUBER_CLAMP
+    return __builtin_amdgcn_fmed3f(__frsqrt_rn(y), 0.0f, 1.0f);      // folded into the rsq's clamp bit (no inline asm:
+                                                                     // the compiler keeps track of the trans-use hazard)
+#else
+    return fminf(__frsqrt_rn(y), 1.0f);
+#endif
+}
+__device__ __forceinline__ f2 vrsq_min1(f2 y) { return f2{vrsq_min1(y.x), vrsq_min1(y.y)}; }
 // select(y <= 1, a, b)
 __device__ __forceinline__ float vsel_le1(float y, float a, float b) { return y <= 1.0f ? a : b; }
 __device__ __forceinline__ f2 vsel_le1(f2 y, f2 a, f2 b) {
@@ -179,7 +199,7 @@ __device__ __forceinline__ F huber_accumulate(F x2, float inv_a2, F conf, F& cos
     cost_acc = vfma(vsel_le1(y, y, vfma(2.0f * (y + 1e-8f), isx, vsplat(y, -1.0f))), conf, cost_acc);
     return weight * conf;
 #else
-    const F weight = vmin1(vrsq(y));
+    const F weight = vrsq_min1(y);
     const F wc = weight * conf;
     cost_acc = vfma(y * wc, 2.0f - weight, cost_acc);
     return wc;
@@ -318,6 +338,17 @@ __device__ __forceinline__ void radial_terms(const PBlock& P, F r2, Radial<F>& R
     }
 }
 
+// |q|^2 kept away from 0 for the rsq behind it (the reference normalises with an epsilon as well, misc.py:275-276): the
+// 1e-24 rides in the fma chain -- it vanishes in the rounding unless |q|^2 < 1e-17 -- instead of a v_max_f32 per pixel.
+template <typename F>
+__device__ __forceinline__ F norm2_eps(F qx, F qy) {
+#if GCLM_EPS_FMA
+    return vfma(qx, qx, vfma(qy, qy, vsplat(qx, 1e-24f)));
+#else
+    return vmax(vfma(qx, qx, qy * qy), vsplat(qx, 1e-24f));
+#endif
+}
+
 template <int MODEL>
 struct Layout {
     static constexpr int PM = acc_pm(MODEL);            // full columns of the record (4, radial 5)
@@ -373,7 +404,7 @@ __device__ __forceinline__ void pixel_accumulate_fast(const PBlock& P, const Hub
             qx = vfma(d, px, kt * u);
             qy = vfma(d, vsplat(u, py), kt * v);
         }
-        const F n2 = vmax(vfma(qx, qx, qy * qy), vsplat(u, 1e-24f));
+        const F n2 = norm2_eps(qx, qy);
         const F rn = vrsq(n2);
         const F ux = qx * rn, uy = qy * rn;              // predicted up vector
         const F rx = dux - ux, ry = duy - uy;            // residual (lm_optimizer.py:266)
@@ -439,14 +470,24 @@ __device__ __forceinline__ void pixel_accumulate_fast(const PBlock& P, const Hub
         }
         const F nn = DIST ? vfma(e, er2, vsplat(u, 1.0f)) : r2 + 1.0f;      // |(e u, e v, 1)|^2
         const F rnn = vrsq(nn);
-        const F ern = DIST ? e * rnn : rnn;
         const F guv = vfma(u, vsplat(u, P.ga), vsplat(u, v * P.gb));          // g_xy . uv
-        const F s = vfma(ern, guv, rnn * P.gc);                              // ray . g
+        F s, l0, l1;
+        const F uT0 = vfma(u, vsplat(u, P.T00), vsplat(u, v * P.T10)), uT1 = vfma(u, vsplat(u, P.T01), vsplat(u, v * P.T11));
+        if constexpr (DIST && GCLM_RAY_FACTORED) {
+            // ray . x = rnn (e (x_xy.uv) + x_z): the 1/n factor last -- one op per pixel pair less than
+            // (e rnn)(x_xy.uv) + rnn x_z, which needs e rnn (pinhole: e = 1, no difference; it keeps the form below)
+            s = vfma(e, guv, vsplat(u, P.gc)) * rnn;                                                // ray . g
+            l0 = vfma(e, uT0, vsplat(u, P.T20)) * rnn;                                              // ray . T[:,0]
+            l1 = vfma(e, uT1, vsplat(u, P.T21)) * rnn;
+        } else {
+            const F ern = DIST ? e * rnn : rnn;
+            s = vfma(ern, guv, rnn * P.gc);
+            l0 = vfma(ern, uT0, rnn * P.T20);
+            l1 = vfma(ern, uT1, rnn * P.T21);
+        }
         const F sc = vclamp(s, -1.0f + 1e-6f, 1.0f - 1e-6f);
         const F rl = slat - sc;                          // lm_optimizer.py:262,270-271 (slat = sin(latitude_field))
         const F wgt = huber_accumulate(rl * rl, hk.inv_a2l, cl, acc[A_CL]);
-        const F l0 = vfma(ern, vfma(u, vsplat(u, P.T00), vsplat(u, v * P.T10)), rnn * P.T20);   // ray . T[:,0]
-        const F l1 = vfma(ern, vfma(u, vsplat(u, P.T01), vsplat(u, v * P.T11)), rnn * P.T21);
         // h = (g_xy - s ray_xy)/n;  ds/df = h.(e w - 2 k1 (u,v)(uv.w)),  ds/dk1 = h.(-r2 (u,v))   (perspective_fields.py:255-272)
         //   h.uv = rnn (g_xy.uv - s ern r2),   h.w = rnn (g_xy.w - s ern (uv.w))
         F l2;
@@ -460,7 +501,7 @@ __device__ __forceinline__ void pixel_accumulate_fast(const PBlock& P, const Hub
             }
         } else {
             const F gw = vfma(wx, vsplat(u, P.ga), vsplat(u, wy * P.gb));
-            const F hw = vfma(-s, ern * uvw, gw) * rnn;
+            const F hw = vfma(-s, (DIST ? e * rnn : rnn) * uvw, gw) * rnn;
             l2 = hw;
             if constexpr (DIST) l2 = vfma(e, hw, -((uvw * k1x2) * hu));
         }
@@ -525,7 +566,7 @@ __device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& 
             qx = vfma(R.s, px, kt * u);
             qy = vfma(R.s, vsplat(u, py), kt * v);
         }
-        const F n2 = vmax(vfma(qx, qx, qy * qy), vsplat(u, 1e-24f));
+        const F n2 = norm2_eps(qx, qy);
         const F rn = vrsq(n2);
         const F ux = qx * rn, uy = qy * rn;              // predicted up vector
         const F rx = dux - ux, ry = duy - uy;            // residual (lm_optimizer.py:266)
