@@ -450,9 +450,10 @@ static int run_solve(gclm_handle* h, const float* d_up, const float* d_lat, cons
     if (int rc = ensure_workspace(h, B, geo.nchunks, c.n_groups)) return rc;
     h->sh.active = false;
 
-    GCLM_HIP(h, launch_init(c, ia, s));
     const bool es = h->cfg.early_stop != 0;
-    if (use_fused(h, B, geo)) {
+    const bool fused_path = use_fused(h, B, geo);
+    if (!fused_path) GCLM_HIP(h, launch_init(c, ia, s));      // (the one-launch-per-step path builds theta_0 in its first launch)
+    if (fused_path) {
         // init | fused(step) x num_steps | fused(final) | finalize : num_steps + 3 launches, partial records double-buffered
         float* const part[2] = {c.partials, c.partials2};
         // Paced launches (single image with early stop): the launches after the stop are skipped on the device, but each
@@ -500,6 +501,8 @@ static int run_solve(gclm_handle* h, const float* d_up, const float* d_lat, cons
             f.partials_in = part[(step + 1) & 1];
             f.progress = (paced && !fin) ? h->progress_dev : nullptr;
             f.epoch = h->epoch;
+            f.ia = ia;
+            f.init_here = step == 0 ? 1 : 0;
             if (int rc = timed_sweep(h, a, s, &f)) return rc;
         }
         SolveCtx cf = c;

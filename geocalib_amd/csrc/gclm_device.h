@@ -70,19 +70,30 @@ __device__ inline V3 from_rp(float roll, float pitch) {   // gravity.py:31-40
     return normalize3({-sr * cp, -cr * cp, sp});
 }
 
-// Gravity.update (gravity.py:112-119) / SphericalManifold.plus (misc.py:234-259)
-__device__ inline V3 grav_update(V3 g, float d0, float d1, bool spherical) {
-    if (!spherical) return from_rp(grav_roll(g) + d0, grav_pitch(g) + d1);
+// Gravity.update (gravity.py:112-119) / SphericalManifold.plus (misc.py:234-259), in two halves: what depends on the OLD
+// gravity only (its norm and Householder vector) and what needs the step.  The one-launch-per-step kernel computes the
+// first half on another wave while the normal equations are still being solved (same operations, same bits).
+struct GravPre {
+    float v[3], beta, nx;
+};
+__device__ inline void grav_update_pre(V3 g, GravPre& p) {
+    p.nx = sqrtf(g.x * g.x + g.y * g.y + g.z * g.z);
+    householder(g, p.v, p.beta);
+}
+__device__ inline V3 grav_update_post(const GravPre& p, float d0, float d1) {
     const float eps = 1e-7f;
-    const float nx = sqrtf(g.x * g.x + g.y * g.y + g.z * g.z);
     const float nd = sqrtf(d0 * d0 + d1 * d1);
     const float nd_ = nd < eps ? nd + eps : nd;
     const float sinc = nd < eps ? 1.f : sinf(nd_) / nd_;
     const float e[3] = {sinc * d0, sinc * d1, cosf(nd)};
-    float v[3], beta;
-    householder(g, v, beta);
-    const float bd = beta * (v[0] * e[0] + v[1] * e[1] + v[2] * e[2]);
-    return normalize3({nx * (e[0] - v[0] * bd), nx * (e[1] - v[1] * bd), nx * (e[2] - v[2] * bd)});
+    const float bd = p.beta * (p.v[0] * e[0] + p.v[1] * e[1] + p.v[2] * e[2]);
+    return normalize3({p.nx * (e[0] - p.v[0] * bd), p.nx * (e[1] - p.v[1] * bd), p.nx * (e[2] - p.v[2] * bd)});
+}
+__device__ inline V3 grav_update(V3 g, float d0, float d1, bool spherical) {
+    if (!spherical) return from_rp(grav_roll(g) + d0, grav_pitch(g) + d1);
+    GravPre p;
+    grav_update_pre(g, p);
+    return grav_update_post(p, d0, d1);
 }
 
 // BaseCamera.update_focal (camera.py:136-152): clamp to fov in [5, 150] deg of the image HEIGHT,
@@ -105,16 +116,75 @@ __device__ inline void update_dist(State& s, int camera_model, float d1, float d
     s.k2 = fminf(fmaxf(s.k2 + (camera_model == GCLM_RADIAL ? d2 : d1), -hi), hi);
 }
 
-__device__ inline void build_pblock(const State& s, bool spherical, bool log_focal, PBlock& p) {
-    const V3 g = {s.gx, s.gy, s.gz};
-    float T[3][2];
+// The parameter block of a state, in two halves: the tangent basis of its gravity (the long chain: a Householder vector,
+// or asin / sincos for the (roll, pitch) form) and the rest (two reciprocals).  build_pblock = fill_pblock(tangent).
+__device__ inline void pblock_tangent(V3 g, bool spherical, float (&T)[3][2]) {
     if (spherical) tangent_sphere(g, T); else tangent_rp(g, T);
-    p.ifx = 1.0f / s.fx; p.ify = 1.0f / s.fy; p.cx = s.cx; p.cy = s.cy;
-    p.ga = g.x; p.gb = g.y; p.gc = g.z; p.k1 = s.k1;
+}
+__device__ inline void fill_pblock(const State& s, const float (&T)[3][2], float ifx, float ify, bool log_focal, PBlock& p) {
+    p.ifx = ifx; p.ify = ify; p.cx = s.cx; p.cy = s.cy;
+    p.ga = s.gx; p.gb = s.gy; p.gc = s.gz; p.k1 = s.k1;
     p.T00 = T[0][0]; p.T01 = T[0][1]; p.T10 = T[1][0]; p.T11 = T[1][1]; p.T20 = T[2][0]; p.T21 = T[2][1];
-    p.wfx = log_focal ? 1.0f : 1.0f / s.fx;
-    p.wfy = log_focal ? 1.0f : 1.0f / s.fy;
+    p.wfx = log_focal ? 1.0f : ifx;
+    p.wfy = log_focal ? 1.0f : ify;
     p.k2 = s.k2; p.pad0 = p.pad1 = p.pad2 = 0.f;
+}
+__device__ inline void build_pblock(const State& s, bool spherical, bool log_focal, PBlock& p) {
+    float T[3][2];
+    pblock_tangent({s.gx, s.gy, s.gz}, spherical, T);
+    fill_pblock(s, T, 1.0f / s.fx, 1.0f / s.fy, log_focal, p);
+}
+
+// The initial estimate of image b: the caller's (gclm_solve) or get_trivial_estimation / siclib's heuristic from the priors
+// (gclm_calibrate).  init_kernel runs it once per image; the one-launch-per-step kernel runs it in the prologue of its
+// first launch instead (every workgroup of the image, same bits), which saves a single-image solve the init launch.
+__device__ inline State init_state(const SolveCtx& c, const InitArgs& ia, int b) {
+    State s;
+    V3 g;
+    if (ia.cam) {       // caller-provided initial estimate
+        const float* cm = ia.cam + (size_t)b * GCLM_CAM_STRIDE;
+        s.w = cm[0]; s.h = cm[1]; s.fx = cm[2]; s.fy = cm[3]; s.cx = cm[4]; s.cy = cm[5]; s.k1 = cm[6]; s.k2 = cm[7];
+        g = normalize3({ia.grav[b * 3], ia.grav[b * 3 + 1], ia.grav[b * 3 + 2]});
+    } else {            // get_trivial_estimation (lm_optimizer.py:20-58) + BaseCamera.from_dict (camera.py:49-93)
+        const float h = (float)c.H, w = (float)c.W;
+        const float focal = ia.prior_focal ? ia.prior_focal[b] : 0.7f * fmaxf(h, w);
+        const float vfov = 2.0f * atanf(h / (2.0f * focal));           // focal2fov
+        const float f = h / 2.0f / tanf(vfov / 2.0f);                   // fov2focal
+        s.w = w; s.h = h; s.fy = f; s.cx = w / 2.0f; s.cy = h / 2.0f;
+        s.fx = ia.scales ? f * ia.scales[0] / ia.scales[1] : f;
+        s.k1 = s.k2 = 0.f;
+        if (ia.prior_dist) {
+            const int nd = ia.prior_dist_cols;
+            s.k1 = ia.prior_dist[(size_t)b * nd];
+            if (nd > 1) s.k2 = ia.prior_dist[(size_t)b * nd + 1];
+        }
+        g = V3{-0.0f, -1.0f, 0.0f};                                   // Gravity.from_rp(0, 0)
+        if (c.cfg.heuristic_init && ia.up) {
+            // get_heuristic_estimation (siclib/models/optimization/utils.py:27-82): roll = angle of the up
+            // vector at the image centre, pitch = latitude at the centre, vfov = |lat(top) - lat(bottom)|
+            // on the central column, all clamped; priors still win below
+            const size_t N = (size_t)c.H * c.W;
+            const int yc = c.H / 2, xc = c.W / 2;
+            const float* up = ia.up + (size_t)b * 2 * N;
+            const float* lat = ia.lat + (size_t)b * N;
+            const float d45 = 45.0f / 180.0f * kPi;
+            float roll = -atan2f(up[(size_t)yc * c.W + xc], -up[N + (size_t)yc * c.W + xc]);
+            roll = fminf(fmaxf(roll, -d45), d45);
+            const float pitch = fminf(fmaxf(lat[(size_t)yc * c.W + xc], -d45), d45);
+            float vfov_h = fabsf(lat[xc] - lat[(size_t)(c.H - 1) * c.W + xc]);
+            vfov_h = fminf(fmaxf(vfov_h, 20.0f / 180.0f * kPi), 120.0f / 180.0f * kPi);
+            if (!ia.prior_focal) {
+                const float fh = h / 2.0f / tanf(vfov_h / 2.0f);
+                s.fy = fh;
+                s.fx = ia.scales ? fh * ia.scales[0] / ia.scales[1] : fh;
+            }
+            g = from_rp(roll, pitch);
+        }
+        if (ia.prior_gravity) g = normalize3({ia.prior_gravity[b * 3], ia.prior_gravity[b * 3 + 1], ia.prior_gravity[b * 3 + 2]});
+    }
+    s.gx = g.x; s.gy = g.y; s.gz = g.z;
+    s.lambda = c.cfg.lambda0; s.prev_cost = 0.f; s.fails = 0.f; s.init_cu = s.init_cl = 0.f;
+    return s;
 }
 
 // ---------------------------------------------------------------- small dense algebra
@@ -225,11 +295,18 @@ __device__ inline void cost_bookkeeping(const gclm_config& cfg, Ctrl* ctrl, int 
     if (cost_rules(cfg, step, total, s, update_lambda)) atomicAdd(&ctrl->notclose[step], 1);
 }
 
-// One LM step of one image from its reduced accumulator record, as pure arithmetic on (s, acc): lambda rule +
-// allclose test, damped normal equations over the estimated columns, manifold / focal / distortion update.
-// `s` is the state at `step` on entry and the state at step + 1 on return; returns whether the cost moved.
+// One LM step of one image from its reduced accumulator record, as pure arithmetic on (s, acc), in stages:
+//   lm_solve          lambda rule + allclose test, damped normal equations over the estimated columns -> the steps `dl`
+//                     (updates s.lambda / prev_cost / fails / init_*; returns whether the cost moved)
+//   lm_apply_gravity / lm_apply_focal / lm_apply_dist    manifold / focal / distortion update: independent of each other
+// lm_step runs them in sequence on one thread (update_kernel); the one-launch-per-step kernel runs the three updates on
+// three waves at once (fused_step_kernel).  `s` is the state at `step` on entry and the state at step + 1 on return.
+struct StepDelta {
+    float dg0, dg1, df, dk1, dk2;
+};
 template <int PM>
-__device__ inline bool lm_step(const gclm_config& cfg, int H, int W, int step, State& s, const float (&acc)[kNAccMax]) {
+__device__ inline bool lm_solve(const gclm_config& cfg, int H, int W, int step, State& s, const float (&acc)[kNAccMax],
+                                StepDelta& dl) {
     const float invN = 1.0f / (float)((size_t)H * W);
     float cu, cl;
     const float total = total_cost(acc, invN, true, cu, cl);   // A_CU is 0 without an up field
@@ -256,12 +333,26 @@ __device__ inline bool lm_step(const gclm_config& cfg, int H, int W, int step, S
         for (int i = 0; i < PM; ++i) d[i] = 0.f;     // zero step for THIS image (reference: whole batch)
         s.fails += 1.f;
     }
-    float dg0, dg1, df, dk1, dk2;
-    split_delta<PM>(cfg, d, dg0, dg1, df, dk1, dk2);
-    const V3 g = grav_update({s.gx, s.gy, s.gz}, dg0, dg1, cfg.use_spherical_manifold != 0);
+    split_delta<PM>(cfg, d, dl.dg0, dl.dg1, dl.df, dl.dk1, dl.dk2);
+    return moved;
+}
+__device__ inline void lm_apply_gravity(const gclm_config& cfg, State& s, const StepDelta& dl) {
+    const V3 g = grav_update({s.gx, s.gy, s.gz}, dl.dg0, dl.dg1, cfg.use_spherical_manifold != 0);
     s.gx = g.x; s.gy = g.y; s.gz = g.z;
-    update_focal(s, df, cfg.use_log_focal != 0);
-    if (cfg.camera_model != GCLM_PINHOLE && cfg.estimate_dist) update_dist(s, cfg.camera_model, dk1, dk2);
+}
+__device__ inline void lm_apply_focal(const gclm_config& cfg, State& s, const StepDelta& dl) {
+    update_focal(s, dl.df, cfg.use_log_focal != 0);
+}
+__device__ inline void lm_apply_dist(const gclm_config& cfg, State& s, const StepDelta& dl) {
+    if (cfg.camera_model != GCLM_PINHOLE && cfg.estimate_dist) update_dist(s, cfg.camera_model, dl.dk1, dl.dk2);
+}
+template <int PM>
+__device__ inline bool lm_step(const gclm_config& cfg, int H, int W, int step, State& s, const float (&acc)[kNAccMax]) {
+    StepDelta dl;
+    const bool moved = lm_solve<PM>(cfg, H, W, step, s, acc, dl);
+    lm_apply_gravity(cfg, s, dl);
+    lm_apply_focal(cfg, s, dl);
+    lm_apply_dist(cfg, s, dl);
     return moved;
 }
 
@@ -282,23 +373,43 @@ __device__ inline void update_image(const SolveCtx& c, int step, int b, const fl
 // order; fewer -- one ascending walk.  Double accumulation, fixed order: every caller gets the same bits.  Must be
 // called by all threads of the block; the sums are valid in EVERY thread on return (read back from LDS).
 constexpr int kGroups = 8, kSlots = 32, kStripeMinChunks = 33;
-__device__ inline void reduce_image_partials(const float* image_partials, int nchunks, int nacc, float (&acc)[kNAccMax]) {
+// `after_first_batch()` runs right after the loads of the first batch of records have been ISSUED and before anything waits
+// for them: the caller's own independent loads (the one-launch-per-step kernel's first field values) queue up BEHIND the
+// records, so the reduction does not wait for them (loads return in order).
+// The sums are valid in the threads of WAVE 0 on return (lane i of wave 0 sums slot i over the stripes, v_readlane hands
+// the values to the whole wave): round 3 had every one of the 256 threads read all 8 x 24 doubles back from LDS -- 1 us of
+// LDS bandwidth at the head of every launch of a single-image solve (device trace, profiles/r04_latency_trace.log).
+template <typename Hook>
+__device__ inline void reduce_image_partials(const float* image_partials, int nchunks, int nacc, float (&acc)[kNAccMax],
+                                             Hook&& after_first_batch) {
     __shared__ double sacc1[kGroups][kSlots + 1];
     const int grp = threadIdx.x / kSlots, slot = threadIdx.x % kSlots;
     const bool striped = nchunks >= kStripeMinChunks;
     const int first = striped ? grp : 0, stride = striped ? kGroups : 1;
-    if (slot < nacc && (striped || grp == 0)) {
+    const bool active = slot < nacc && (striped || grp == 0);
+    const float* p = image_partials + slot;
+    // batches of 32 records per thread: the 19 records of a stripe of a single 640x480 image (150 workgroups) are all
+    // in flight together -- one memory round trip; summed in ascending order (the padding adds exact zeros)
+    float v[32];
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int c = first + j * stride;
+            const float t = p[(size_t)min(c, nchunks - 1) * nacc];      // unconditional load (a clamped index), then
+            v[j] = c < nchunks ? t : 0.f;                                // a select: all loads of the batch in flight
+        }
+    }
+    after_first_batch();                                                 // every thread, in uniform control flow
+    if (active) {
         double d = 0.0;
-        const float* p = image_partials + slot;
-        // batches of 32 records per thread: the 19 records of a stripe of a single 640x480 image (150 workgroups) are all
-        // in flight together -- one memory round trip; summed in ascending order (the padding adds exact zeros)
-        for (int c0 = first; c0 < nchunks; c0 += 32 * stride) {
-            float v[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) d += v[j];
+        for (int c0 = first + 32 * stride; c0 < nchunks; c0 += 32 * stride) {
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
                 const int c = c0 + j * stride;
-                const float t = p[(size_t)min(c, nchunks - 1) * nacc];      // unconditional load (a clamped index), then
-                v[j] = c < nchunks ? t : 0.f;                                // a select: all loads of the batch in flight
+                const float t = p[(size_t)min(c, nchunks - 1) * nacc];
+                v[j] = c < nchunks ? t : 0.f;
             }
 #pragma unroll
             for (int j = 0; j < 32; ++j) d += v[j];
@@ -306,15 +417,19 @@ __device__ inline void reduce_image_partials(const float* image_partials, int nc
         sacc1[grp][slot] = d;
     }
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < kNAccMax; ++i) {
+    if (threadIdx.x < 64) {                                            // wave 0 (wave-uniform)
         double d = 0.0;
-        if (i < nacc) {
-            if (striped) { for (int g = 0; g < kGroups; ++g) d += sacc1[g][i]; }
-            else d = sacc1[0][i];
+        if ((int)threadIdx.x < nacc) {
+            if (striped) { for (int g = 0; g < kGroups; ++g) d += sacc1[g][threadIdx.x]; }
+            else d = sacc1[0][threadIdx.x];
         }
-        acc[i] = (float)d;
+        const int mine = __builtin_bit_cast(int, (float)d);            // 0.0f in the lanes beyond nacc
+#pragma unroll
+        for (int i = 0; i < kNAccMax; ++i) acc[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(mine, i));
     }
+}
+__device__ inline void reduce_image_partials(const float* image_partials, int nchunks, int nacc, float (&acc)[kNAccMax]) {
+    reduce_image_partials(image_partials, nchunks, nacc, acc, [] {});
 }
 
 #pragma clang fp contract(fast)

@@ -143,6 +143,8 @@ struct FusedArgs {
     const float* partials_in;   // the partial records of the previous launch (the other half of the double buffer)
     unsigned* progress;         // paced launches (gclm_set_paced_launches): host-mapped word image 0 reports to, or null
     unsigned epoch;             // ... and the tag of this solve in it (stale words of earlier solves are ignored)
+    InitArgs ia;                // step 0: the initial estimate is built in this launch's prologue (no init_kernel launch) ...
+    int init_here;              // ... when set; workgroup 0 of an image commits state[0], image 0's also resets Ctrl
 };
 // the word a paced launch publishes: [31:20] epoch of the solve, bit 16 "the early stop fired here", [15:0] step + 1
 constexpr unsigned kPacedStopBit = 1u << 16;

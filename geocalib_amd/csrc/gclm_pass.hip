@@ -97,6 +97,22 @@
 #define GCLM_DIV_GUARD_ALWAYS 0     // A/B switch: 1 = simple_divisional always runs the guarded body (round-2 behaviour)
 #endif
 
+#ifndef GCLM_TRACE
+#define GCLM_TRACE 0                // measurement build only: device timestamps of one workgroup's stages (scripts/probes/trace_probe.py)
+#endif
+#if GCLM_TRACE
+__device__ unsigned long long g_gclm_trace[64][16];
+#define GCLM_T(step, slot) do { if (threadIdx.x == 0 && blockIdx.x == GCLM_TRACE_WG && blockIdx.y == 0 && (step) < 64) g_gclm_trace[(step)][(slot)] = wall_clock64(); } while (0)
+extern "C" int gclm_debug_trace(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gclm_trace), sizeof(g_gclm_trace)) == hipSuccess ? 0 : -1;
+}
+#ifndef GCLM_TRACE_WG
+#define GCLM_TRACE_WG 0
+#endif
+#else
+#define GCLM_T(step, slot) do {} while (0)
+#endif
+
 namespace gclm {
 
 namespace {
@@ -820,6 +836,109 @@ struct Lane<1> {
     static __device__ __forceinline__ F xcoord(int x, int) { return (float)x; }
 };
 
+// One lane's place in the sweep of an image (a pure function of the launch geometry: nothing here depends on the parameters)
+template <int VEC>
+struct LaneJob {
+    bool live;
+    int y, y_end, xu;
+    uint32_t off, off_step;      // byte offset inside a plane (N < 2^30) and its advance per loop iteration
+};
+template <int VEC>
+__device__ __forceinline__ LaneJob<VEC> lane_job(const SweepArgs& a, const int chunk) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int job = chunk * (kBlock / 64) + wave;        // jobs of an image: (rowblock, strip, wave of the tile)
+    const int tile = job / a.wpt, tw = job - tile * a.wpt;
+    const int rowblock = tile / a.nstrips, strip = tile - rowblock * a.nstrips;
+    const int f = tw * 64 + lane;                        // lane index inside the tile
+    const int tr = f / a.cu, tc = f - tr * a.cu;
+    LaneJob<VEC> j;
+    j.xu = strip * a.cu + tc;                            // unit column of the lane
+    j.live = job < a.jobs && tr < a.rpi && j.xu < a.wu;
+    j.y_end = min((rowblock + 1) * a.rows_per_block, a.H);
+    j.y = rowblock * a.rows_per_block + tr;
+    j.off = ((uint32_t)j.y * (uint32_t)a.W + (uint32_t)(j.xu * VEC)) * 4u;
+    j.off_step = (uint32_t)a.rpi * (uint32_t)a.W * 4u;
+    return j;
+}
+
+// The five values a lane reads per loop iteration (one float4 -- or one pixel -- of every plane)
+template <int VEC>
+struct RowData {
+    typename Lane<VEC>::V vux, vuy, vlat, vcu, vcl;
+};
+template <bool HAS_UP, bool HAS_UPC, bool HAS_LATC, int VEC>
+__device__ __forceinline__ RowData<VEC> load_row(const float* upx, const float* upy, const float* lat, const float* upc,
+                                                 const float* latc, const uint32_t off) {
+    using L = Lane<VEC>;
+    RowData<VEC> r;
+    r.vcu = L::ones();
+    r.vcl = L::ones();
+    if constexpr (HAS_UP) {
+        r.vux = L::ld(upx, off);
+        r.vuy = L::ld(upy, off);
+    }
+    r.vlat = L::ld(lat, off);
+    if constexpr (HAS_UP && HAS_UPC) r.vcu = L::ld(upc, off);
+    if constexpr (HAS_LATC) r.vcl = L::ld(latc, off);
+    return r;
+}
+
+// The math of one loop iteration: image row y of the lane's column(s), from the loaded values into the accumulators
+template <int MODEL, bool HAS_UP, bool LOGF, int VEC>
+__device__ __forceinline__ void row_math(const PBlock& P, const HuberK& hk, const typename Lane<VEC>::F (&col_u)[Lane<VEC>::kPairs],
+                                         const typename Lane<VEC>::F (&col_px)[Lane<VEC>::kPairs], const int y,
+                                         const RowData<VEC>& r, typename Lane<VEC>::F (&acc)[Layout<MODEL>::NACC],
+                                         [[maybe_unused]] const bool col_zero, [[maybe_unused]] const bool div_k_tiny) {
+    using L = Lane<VEC>;
+    using F = typename L::F;
+    // latitudes beyond +-pi/2 (never from the CNN head; a caller's own field may hold them): fold them into the
+    // polynomial's range.  Wave-uniform branch on a ballot: in-range data pays one max3 / max / cmp per 4 pixels.
+    F slat[L::kPairs];
+    {
+        F lt[L::kPairs], t[L::kPairs];
+#pragma unroll
+        for (int k = 0; k < L::kPairs; ++k) { lt[k] = L::get(r.vlat, k); t[k] = lt[k] * lt[k]; }
+        if (__builtin_amdgcn_ballot_w64(L::max_of(t) > kHalfPiSq) != 0) {
+#pragma unroll
+            for (int k = 0; k < L::kPairs; ++k) { lt[k] = L::fold(lt[k]); t[k] = lt[k] * lt[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < L::kPairs; ++k) slat[k] = sin_halfpi(lt[k], t[k]);
+    }
+    const float v = ((float)y - P.cy) * P.ify;
+#if GCLM_NOMATH     // measurement only: the memory-system ceiling of this exact access pattern
+#pragma unroll
+    for (int k = 0; k < L::kPairs; ++k)
+        acc[0] = acc[0] + (HAS_UP ? L::get(r.vux, k) + L::get(r.vuy, k) : F(0.f)) + L::get(r.vlat, k) + L::get(r.vcu, k) + L::get(r.vcl, k);
+    (void)v;
+    (void)hk;
+#else
+    if constexpr (MODEL == GCLM_SIMPLE_DIVISIONAL) {
+        // a guarded denominator of radial_terms can only vanish on the principal point (r2 == 0: this wave holds
+        // it in this iteration) or for k ~ 0 (the first sweep): only then are the guarded terms computed
+        const bool patch = div_k_tiny || __builtin_amdgcn_ballot_w64(col_zero && v == 0.f) != 0;
+#pragma unroll
+        for (int k = 0; k < L::kPairs; ++k)
+            pixel_accumulate<MODEL, HAS_UP, LOGF, F, 0, 1>(P, hk, col_u[k], col_px[k], v, HAS_UP ? L::get(r.vux, k) : F(0.f),
+                                                               HAS_UP ? L::get(r.vuy, k) : F(0.f), slat[k], L::get(r.vcu, k),
+                                                               L::get(r.vcl, k), acc, nullptr, nullptr, patch);
+    } else {
+#pragma unroll
+        for (int k = 0; k < L::kPairs; ++k) {
+            if constexpr (MODEL == GCLM_PINHOLE || MODEL == GCLM_SIMPLE_RADIAL)
+                pixel_accumulate_fast<MODEL, HAS_UP, LOGF, F>(P, hk, col_u[k], col_px[k], v, HAS_UP ? L::get(r.vux, k) : F(0.f),
+                                                        HAS_UP ? L::get(r.vuy, k) : F(0.f), slat[k],
+                                                        L::get(r.vcu, k), L::get(r.vcl, k), acc);
+            else
+                pixel_accumulate<MODEL, HAS_UP, LOGF, F>(P, hk, col_u[k], col_px[k], v, HAS_UP ? L::get(r.vux, k) : F(0.f),
+                                                   HAS_UP ? L::get(r.vuy, k) : F(0.f), slat[k], L::get(r.vcu, k),
+                                                   L::get(r.vcl, k), acc);
+        }
+    }
+#endif
+}
+
 // COLUMN-STATIONARY mapping.  The unit of work is a WAVE JOB: 64 consecutive lanes of a tile of `rpi` rows x `cu`
 // units (float4 groups, or pixels in the scalar path) of ONE image, walking down `rows_per_block` rows, `rpi` rows
 // per iteration; lane f of the tile sits at (row f / cu, unit f % cu) and NEVER changes its column.  With a single
@@ -830,8 +949,13 @@ struct Lane<1> {
 // only -- u = (x - cx)/fx, p_x = ga - gc u, the int -> float conversions behind them -- leaves the loop, the byte
 // offset advances by a wave-uniform constant, and the loop bookkeeping is one add and one compare (the row-major
 // streaming it replaced spent ~21 of 295 VALU instructions per 4 pixels on these; scripts/isa_stats.py).
-template <int MODEL, bool HAS_UP, bool HAS_UPC, bool HAS_LATC, bool LOGF, int VEC>
-__device__ __forceinline__ void sweep_body(const SweepArgs& a, const PBlock& P, const int b, const int chunk) {
+//
+// PRE > 0 (one-launch-per-step kernel only): the values of the lane's first PRE iterations were requested by the caller
+// before its prologue (`pre`, with the lane's job `pj`), so their memory round trip runs under the prologue's.
+template <int MODEL, bool HAS_UP, bool HAS_UPC, bool HAS_LATC, bool LOGF, int VEC, int PRE = 0>
+__device__ __forceinline__ void sweep_body(const SweepArgs& a, const PBlock& P, const int b, const int chunk,
+                                           [[maybe_unused]] const LaneJob<VEC>* pj = nullptr,
+                                           [[maybe_unused]] const RowData<VEC>* pre = nullptr) {
     constexpr int NACC = Layout<MODEL>::NACC;
     const int tid = threadIdx.x;
     HuberK hk;
@@ -849,24 +973,19 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const PBlock& P, 
 
     using L = Lane<VEC>;
     using F = typename L::F;
-    using V = typename L::V;
     F acc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = F(0.f);
 
     // this wave's job, the lane's place in its tile (once per kernel), its column terms, its first row
     const int lane = tid & 63, wave = tid >> 6;
-    const int job = chunk * (kBlock / 64) + wave;        // jobs of an image: (rowblock, strip, wave of the tile)
-    const int tile = job / a.wpt, tw = job - tile * a.wpt;
-    const int rowblock = tile / a.nstrips, strip = tile - rowblock * a.nstrips;
-    const int f = tw * 64 + lane;                        // lane index inside the tile
-    const int tr = f / a.cu, tc = f - tr * a.cu;
-    const int xu = strip * a.cu + tc;                    // unit column of the lane
-    const bool live = job < a.jobs && tr < a.rpi && xu < a.wu;
-    const int y_end = min((rowblock + 1) * a.rows_per_block, a.H);
-    int y = rowblock * a.rows_per_block + tr;
-    uint32_t off = ((uint32_t)y * (uint32_t)a.W + (uint32_t)(xu * VEC)) * 4u;      // byte offset inside a plane (N < 2^30)
-    const uint32_t off_step = (uint32_t)a.rpi * (uint32_t)a.W * 4u;
+    const LaneJob<VEC> j = PRE > 0 ? *pj : lane_job<VEC>(a, chunk);
+    const int xu = j.xu;
+    const bool live = j.live;
+    const int y_end = j.y_end;
+    int y = j.y;
+    uint32_t off = j.off;
+    const uint32_t off_step = j.off_step;
     F col_u[L::kPairs], col_px[L::kPairs];
 #pragma unroll
     for (int k = 0; k < L::kPairs; ++k) {
@@ -881,63 +1000,22 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const PBlock& P, 
         for (int k = 0; k < L::kPairs; ++k) col_zero = col_zero || L::any_zero(col_u[k]);
     }
     if (live) {
-        for (; y < y_end; y += a.rpi, off += off_step) {
-            V vux, vuy, vcu = L::ones(), vcl = L::ones();
-            if constexpr (HAS_UP) {
-                vux = L::ld(upx, off);
-                vuy = L::ld(upy, off);
+        if constexpr (PRE > 0) {
+#pragma unroll
+            for (int it = 0; it < PRE; ++it) {
+                if (y < y_end) {
+                    row_math<MODEL, HAS_UP, LOGF, VEC>(P, hk, col_u, col_px, y, pre[it], acc, col_zero, div_k_tiny);
+                    y += a.rpi;
+                    off += off_step;
+                }
             }
-            const V vlat = L::ld(lat, off);
-            if constexpr (HAS_UP && HAS_UPC) vcu = L::ld(upc, off);
-            if constexpr (HAS_LATC) vcl = L::ld(latc, off);
+        }
+        for (; y < y_end; y += a.rpi, off += off_step) {
+            const RowData<VEC> r = load_row<HAS_UP, HAS_UPC, HAS_LATC, VEC>(upx, upy, lat, upc, latc, off);
             // keep every load of the iteration ahead of the math: left alone, the scheduler sinks loads next to
             // their first use to save registers in some instantiations (load -> wait -> use, five times over)
             __builtin_amdgcn_sched_barrier(0);
-            // latitudes beyond +-pi/2 (never from the CNN head; a caller's own field may hold them): fold them into the
-            // polynomial's range.  Wave-uniform branch on a ballot: in-range data pays one max3 / max / cmp per 4 pixels.
-            F slat[L::kPairs];
-            {
-                F lt[L::kPairs], t[L::kPairs];
-#pragma unroll
-                for (int k = 0; k < L::kPairs; ++k) { lt[k] = L::get(vlat, k); t[k] = lt[k] * lt[k]; }
-                if (__builtin_amdgcn_ballot_w64(L::max_of(t) > kHalfPiSq) != 0) {
-#pragma unroll
-                    for (int k = 0; k < L::kPairs; ++k) { lt[k] = L::fold(lt[k]); t[k] = lt[k] * lt[k]; }
-                }
-#pragma unroll
-                for (int k = 0; k < L::kPairs; ++k) slat[k] = sin_halfpi(lt[k], t[k]);
-            }
-            const float v = ((float)y - P.cy) * P.ify;
-#if GCLM_NOMATH     // measurement only: the memory-system ceiling of this exact access pattern
-#pragma unroll
-            for (int k = 0; k < L::kPairs; ++k)
-                acc[0] = acc[0] + (HAS_UP ? L::get(vux, k) + L::get(vuy, k) : F(0.f)) + L::get(vlat, k) + L::get(vcu, k) + L::get(vcl, k);
-            (void)v;
-            (void)hk;
-#else
-            if constexpr (MODEL == GCLM_SIMPLE_DIVISIONAL) {
-                // a guarded denominator of radial_terms can only vanish on the principal point (r2 == 0: this wave holds
-                // it in this iteration) or for k ~ 0 (the first sweep): only then are the guarded terms computed
-                const bool patch = div_k_tiny || __builtin_amdgcn_ballot_w64(col_zero && v == 0.f) != 0;
-#pragma unroll
-                for (int k = 0; k < L::kPairs; ++k)
-                    pixel_accumulate<MODEL, HAS_UP, LOGF, F, 0, 1>(P, hk, col_u[k], col_px[k], v, HAS_UP ? L::get(vux, k) : F(0.f),
-                                                                       HAS_UP ? L::get(vuy, k) : F(0.f), slat[k], L::get(vcu, k),
-                                                                       L::get(vcl, k), acc, nullptr, nullptr, patch);
-            } else {
-#pragma unroll
-                for (int k = 0; k < L::kPairs; ++k) {
-                    if constexpr (MODEL == GCLM_PINHOLE || MODEL == GCLM_SIMPLE_RADIAL)
-                        pixel_accumulate_fast<MODEL, HAS_UP, LOGF, F>(P, hk, col_u[k], col_px[k], v, HAS_UP ? L::get(vux, k) : F(0.f),
-                                                                HAS_UP ? L::get(vuy, k) : F(0.f), slat[k],
-                                                                L::get(vcu, k), L::get(vcl, k), acc);
-                    else
-                        pixel_accumulate<MODEL, HAS_UP, LOGF, F>(P, hk, col_u[k], col_px[k], v, HAS_UP ? L::get(vux, k) : F(0.f),
-                                                           HAS_UP ? L::get(vuy, k) : F(0.f), slat[k], L::get(vcu, k),
-                                                           L::get(vcl, k), acc);
-                }
-            }
-#endif
+            row_math<MODEL, HAS_UP, LOGF, VEC>(P, hk, col_u, col_px, y, r, acc, col_zero, div_k_tiny);
         }
     }
 
@@ -1016,39 +1094,151 @@ __global__ __launch_bounds__(kBlock) void fused_step_kernel(const SweepArgs a, c
     const SolveCtx& c = f.c;
     const gclm_config& cfg = c.cfg;
     const int b = blockIdx.y, chunk = blockIdx.x, step = f.step;      // this launch sweeps theta_step (final: theta_final)
+    GCLM_T(step, 0);
     __shared__ PBlock Ps;
     __shared__ int go;
     int stop_j = 0;                                                    // > 0: the stop fired after update stop_j (earlier launch)
     if (cfg.early_stop) {
         if (!f.is_final) {
-            // every launch after the one that detected the stop leaves its counter at 0 too (see Ctrl)
+            // every launch after the one that detected the stop leaves its counter at 0 too (see Ctrl).  (Testing the counter
+            // only after the partial records have been requested as well -- one round trip instead of two -- was measured: the
+            // active launches gain nothing, the skipped ones cost 3.0 instead of 2.3 us each; profiles/r04_latency_trace.log.)
             if (step >= 3 && c.ctrl->notclose[step - 2] == 0) return;
         } else {
-            for (int j = 1; j <= step - 2; ++j)
-                if (c.ctrl->notclose[j] == 0) { stop_j = j; break; }
+            // the first counter in [1, step - 2] that stayed 0: all of them in one round trip, 64 per wave-load
+            const int lane = threadIdx.x & 63;
+            for (int j0 = 1; j0 <= step - 2 && stop_j == 0; j0 += 64) {
+                const int j = j0 + lane;
+                const int v = j <= step - 2 ? c.ctrl->notclose[j] : 1;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(v == 0);
+                if (m) stop_j = j0 + __builtin_ctzll(m);
+            }
         }
     }
+    // The lane's first kFusedPre loop iterations are REQUESTED here, before the prologue: which bytes a lane reads depends on
+    // the launch geometry only, not on the parameters, so their memory round trip (~1.5 us of a 2.3 us single-image sweep)
+    // runs under the round trip of the partial records instead of after the parameter block is built.  A single image is cut
+    // into two iterations per workgroup (plan_geometry), i.e. everything it reads is in flight before the update starts.
+    constexpr int kFusedPre = 2;
+    const LaneJob<4> pj = lane_job<4>(a, chunk);
+    RowData<4> pre[kFusedPre];
+    auto request_fields = [&]() {
+        const size_t N = (size_t)a.H * a.W;
+        const float* upx = HAS_UP ? a.up + (size_t)b * 2 * N : nullptr;
+        const float* upy = HAS_UP ? upx + N : nullptr;
+        const float* lat = a.lat + (size_t)b * N;
+        const float* upc = HAS_UPC ? a.upc + (size_t)b * N : nullptr;
+        const float* latc = HAS_LATC ? a.latc + (size_t)b * N : nullptr;
+#pragma unroll
+        for (int it = 0; it < kFusedPre; ++it) {
+            pre[it].vux = pre[it].vuy = pre[it].vlat = pre[it].vcu = pre[it].vcl = Lane<4>::ones();
+            if (pj.live && pj.y + it * a.rpi < pj.y_end)
+                pre[it] = load_row<HAS_UP, HAS_UPC, HAS_LATC, 4>(upx, upy, lat, upc, latc, pj.off + (uint32_t)it * pj.off_step);
+        }
+    };
     State fin;                                                         // thread 0: the state this launch sweeps at
     bool commit = false, moved = false, stop_now = false;
+    bool parts = false;                                                // tangent basis / reciprocals already in LDS
+    const bool sph = cfg.use_spherical_manifold != 0;
+    // The update of step - 1 is a serial chain per image (reduction -> lambda rule -> damped Cholesky -> manifold / focal /
+    // distortion update -> tangent basis of the new gravity): ~4 us on one lane, on the critical path of every launch of a
+    // single-image solve.  Its independent pieces run on the leaders of three WAVES (different SIMDs of the CU) at once:
+    //   while thread 0 solves the normal equations, thread 64 prepares what the manifold update needs of the OLD gravity;
+    //   then thread 0: new gravity + its tangent basis | thread 64: new focal + reciprocals | thread 128: new distortion.
+    // The operations and their order per quantity are those of lm_step / build_pblock (gclm_device.h), so the result is the
+    // two-launch path's bit for bit (test_one_launch_per_step_equals_the_two_launch_sequence).
+    __shared__ StepDelta sh_dl;
+    __shared__ GravPre sh_pre;
+    __shared__ int sh_stop;
+    __shared__ float sh_T[3][2], sh_g[3], sh_f[4], sh_k[2];
     if (step > 0 && stop_j == 0) {
+        const int tid = threadIdx.x;
         State prev{};
-        if (threadIdx.x == 0) prev = c.state[(step - 1) & 1][b];      // in flight together with the partial records
+        if (tid == 0 || tid == 64 || tid == 128) prev = c.state[(step - 1) & 1][b];   // in flight together with the partial records
         float acc[kNAccMax];
-        reduce_image_partials(f.partials_in + (size_t)b * a.nchunks * NACC, a.nchunks, NACC, acc);
-        if (threadIdx.x == 0) {
+        // (the field values are requested BEHIND the partial records: the reduction then does not wait for them)
+        reduce_image_partials(f.partials_in + (size_t)b * a.nchunks * NACC, a.nchunks, NACC, acc, request_fields);
+        GCLM_T(step, 1);
+        if (tid == 0) {
             fin = prev;
-            moved = lm_step<PM>(cfg, c.H, c.W, step - 1, fin, acc);
+            StepDelta dl;
+            moved = lm_solve<PM>(cfg, c.H, c.W, step - 1, fin, acc, dl);
+            GCLM_T(step, 2);
             stop_now = cfg.early_stop && step - 1 >= 1 && !moved;     // B == 1: this image IS the batch (:619-625)
-            if (stop_now) fin = prev;                                  // the tentative theta_step is discarded
+            sh_dl = dl;
+            sh_stop = stop_now ? 1 : 0;
+        } else if (tid == 64 && sph) {
+            GravPre pre;
+            grav_update_pre({prev.gx, prev.gy, prev.gz}, pre);
+            sh_pre = pre;
+        }
+        __syncthreads();
+        GCLM_T(step, 3);
+        const bool stop_all = sh_stop != 0;                            // block-uniform
+        if (!stop_all || f.is_final) {                                 // (a stop in a loop launch: nobody sweeps, nothing to build)
+            if (tid == 0) {
+                V3 g = {prev.gx, prev.gy, prev.gz};
+                if (!stop_all) {
+                    const StepDelta dl = sh_dl;
+                    if (sph) { const GravPre pre = sh_pre; g = grav_update_post(pre, dl.dg0, dl.dg1); }
+                    else g = grav_update(g, dl.dg0, dl.dg1, false);
+                }
+                float T[3][2];
+                pblock_tangent(g, f.is_final ? false : sph, T);
+                sh_g[0] = g.x; sh_g[1] = g.y; sh_g[2] = g.z;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { sh_T[i][0] = T[i][0]; sh_T[i][1] = T[i][1]; }
+            } else if (tid == 64) {
+                State t = prev;
+                if (!stop_all) lm_apply_focal(cfg, t, sh_dl);
+                sh_f[0] = t.fx; sh_f[1] = t.fy; sh_f[2] = 1.0f / t.fx; sh_f[3] = 1.0f / t.fy;
+            } else if (tid == 128) {
+                State t = prev;
+                if (!stop_all) lm_apply_dist(cfg, t, sh_dl);
+                sh_k[0] = t.k1; sh_k[1] = t.k2;
+            }
+            __syncthreads();
+            GCLM_T(step, 4);
+            parts = true;
+        }
+        if (tid == 0) {
+            if (stop_now) {
+                fin = prev;                                            // the tentative theta_step is discarded
+            } else {
+                fin.gx = sh_g[0]; fin.gy = sh_g[1]; fin.gz = sh_g[2];
+                fin.fx = sh_f[0]; fin.fy = sh_f[1]; fin.k1 = sh_k[0]; fin.k2 = sh_k[1];
+            }
             commit = !stop_now;
         }
-    } else if (threadIdx.x == 0) {
-        fin = c.state[stop_j > 0 ? (stop_j & 1) : 0][b];               // an earlier stop's theta_j, or theta_0 (num_steps == 0)
+    } else {
+        request_fields();
+        if (step == 0 && f.init_here) {
+            // the first launch of a solve builds the initial estimate itself (every workgroup of the image, same bits) instead
+            // of reading what an init_kernel launch left: one launch less at the head of a single-image solve.  Nothing in
+            // THIS launch reads Ctrl's counters (step 0), later launches find them reset (stream order).
+            if (chunk == 0 && b == 0) {
+                for (int i = threadIdx.x; i < GCLM_MAX_STEPS + 4; i += kBlock) c.ctrl->notclose[i] = 0;
+                if (threadIdx.x == 0) { c.ctrl->stopped = 0; c.ctrl->final_sel = cfg.num_steps & 1; }
+            }
+            if (threadIdx.x == 0) {
+                fin = init_state(c, f.ia, b);
+                if (chunk == 0) c.state[0][b] = fin;
+            }
+        } else if (threadIdx.x == 0) {
+            fin = c.state[stop_j > 0 ? (stop_j & 1) : 0][b];           // an earlier stop's theta_j, or theta_0 (num_steps == 0)
+        }
     }
     if (threadIdx.x == 0) {
         PBlock p;
-        if (f.is_final) build_pblock(fin, false, c.iso_final != 0, p);
-        else build_pblock(fin, cfg.use_spherical_manifold != 0, cfg.use_log_focal != 0, p);
+        const bool lf = f.is_final ? c.iso_final != 0 : cfg.use_log_focal != 0;
+        if (parts) {
+            float T[3][2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { T[i][0] = sh_T[i][0]; T[i][1] = sh_T[i][1]; }
+            fill_pblock(fin, T, sh_f[2], sh_f[3], lf, p);
+        } else {
+            build_pblock(fin, f.is_final ? false : sph, lf, p);
+        }
         Ps = p;
         go = (f.is_final || !stop_now) ? 1 : 0;
         if (chunk == 0) {
@@ -1069,6 +1259,7 @@ __global__ __launch_bounds__(kBlock) void fused_step_kernel(const SweepArgs a, c
         }
     }
     __syncthreads();
+    GCLM_T(step, 5);
     if (!go) return;
     // workgroup-uniform parameter block: LDS -> SGPRs (the sweep addresses it as scalar operands)
     PBlock P;
@@ -1080,7 +1271,8 @@ __global__ __launch_bounds__(kBlock) void fused_step_kernel(const SweepArgs a, c
         P.T20 = uni(Ps.T20); P.T21 = uni(Ps.T21); P.wfx = uni(Ps.wfx); P.wfy = uni(Ps.wfy);
         P.k2 = uni(Ps.k2); P.pad0 = P.pad1 = P.pad2 = 0.f;
     }
-    sweep_body<MODEL, HAS_UP, HAS_UPC, HAS_LATC, LOGF, 4>(a, P, b, chunk);
+    sweep_body<MODEL, HAS_UP, HAS_UPC, HAS_LATC, LOGF, 4, kFusedPre>(a, P, b, chunk, &pj, pre);
+    GCLM_T(step, 6);
 }
 
 // Per-pixel Jacobian fields of the prediction (perspective_fields.py:323-365), the reference's

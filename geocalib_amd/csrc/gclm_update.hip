@@ -74,51 +74,7 @@ __global__ void init_kernel(SolveCtx c, InitArgs ia) {
         for (int i = 0; i < GCLM_MAX_STEPS + 4; ++i) c.ctrl->notclose[i] = 0;
     }
     if (b >= c.B) return;
-    State s;
-    V3 g;
-    if (ia.cam) {       // caller-provided initial estimate
-        const float* cm = ia.cam + (size_t)b * GCLM_CAM_STRIDE;
-        s.w = cm[0]; s.h = cm[1]; s.fx = cm[2]; s.fy = cm[3]; s.cx = cm[4]; s.cy = cm[5]; s.k1 = cm[6]; s.k2 = cm[7];
-        g = normalize3({ia.grav[b * 3], ia.grav[b * 3 + 1], ia.grav[b * 3 + 2]});
-    } else {            // get_trivial_estimation (lm_optimizer.py:20-58) + BaseCamera.from_dict (camera.py:49-93)
-        const float h = (float)c.H, w = (float)c.W;
-        const float focal = ia.prior_focal ? ia.prior_focal[b] : 0.7f * fmaxf(h, w);
-        const float vfov = 2.0f * atanf(h / (2.0f * focal));           // focal2fov
-        const float f = h / 2.0f / tanf(vfov / 2.0f);                   // fov2focal
-        s.w = w; s.h = h; s.fy = f; s.cx = w / 2.0f; s.cy = h / 2.0f;
-        s.fx = ia.scales ? f * ia.scales[0] / ia.scales[1] : f;
-        s.k1 = s.k2 = 0.f;
-        if (ia.prior_dist) {
-            const int nd = ia.prior_dist_cols;
-            s.k1 = ia.prior_dist[(size_t)b * nd];
-            if (nd > 1) s.k2 = ia.prior_dist[(size_t)b * nd + 1];
-        }
-        g = V3{-0.0f, -1.0f, 0.0f};                                   // Gravity.from_rp(0, 0)
-        if (c.cfg.heuristic_init && ia.up) {
-            // get_heuristic_estimation (siclib/models/optimization/utils.py:27-82): roll = angle of the up
-            // vector at the image centre, pitch = latitude at the centre, vfov = |lat(top) - lat(bottom)|
-            // on the central column, all clamped; priors still win below
-            const size_t N = (size_t)c.H * c.W;
-            const int yc = c.H / 2, xc = c.W / 2;
-            const float* up = ia.up + (size_t)b * 2 * N;
-            const float* lat = ia.lat + (size_t)b * N;
-            const float d45 = 45.0f / 180.0f * kPi;
-            float roll = -atan2f(up[(size_t)yc * c.W + xc], -up[N + (size_t)yc * c.W + xc]);
-            roll = fminf(fmaxf(roll, -d45), d45);
-            const float pitch = fminf(fmaxf(lat[(size_t)yc * c.W + xc], -d45), d45);
-            float vfov_h = fabsf(lat[xc] - lat[(size_t)(c.H - 1) * c.W + xc]);
-            vfov_h = fminf(fmaxf(vfov_h, 20.0f / 180.0f * kPi), 120.0f / 180.0f * kPi);
-            if (!ia.prior_focal) {
-                const float fh = h / 2.0f / tanf(vfov_h / 2.0f);
-                s.fy = fh;
-                s.fx = ia.scales ? fh * ia.scales[0] / ia.scales[1] : fh;
-            }
-            g = from_rp(roll, pitch);
-        }
-        if (ia.prior_gravity) g = normalize3({ia.prior_gravity[b * 3], ia.prior_gravity[b * 3 + 1], ia.prior_gravity[b * 3 + 2]});
-    }
-    s.gx = g.x; s.gy = g.y; s.gz = g.z;
-    s.lambda = c.cfg.lambda0; s.prev_cost = 0.f; s.fails = 0.f; s.init_cu = s.init_cl = 0.f;
+    const State s = init_state(c, ia, b);
     c.state[0][b] = s;
     PBlock p;
     build_pblock(s, c.cfg.use_spherical_manifold != 0, c.cfg.use_log_focal != 0, p);
