@@ -282,8 +282,11 @@ __device__ inline bool cost_rules(const gclm_config& cfg, int step, float total,
             const float nl = s.lambda * (total > s.prev_cost ? 10.f : 0.1f);
             s.lambda = fminf(fmaxf(nl, 1e-6f), 1e2f);
         }
-        const double diff = fabs((double)total - (double)s.prev_cost);
-        moved = !(diff <= (double)cfg.atol + (double)cfg.rtol * fabs((double)s.prev_cost));
+        // torch.allclose evaluates |new - prev| <= atol + |rtol * prev| in the tensors' dtype (float32: the scalar tolerances
+        // do not promote; ATen isclose) -- so does this (rounds 1-3 used double: same decision unless the difference sits
+        // within 1e-15 of the threshold, but it was a deviation nobody had written down)
+        const float diff = fabsf(total - s.prev_cost);
+        moved = !(diff <= cfg.atol + fabsf(cfg.rtol * s.prev_cost));
     }
     s.prev_cost = total;
     return moved;

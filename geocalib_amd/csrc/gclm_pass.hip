@@ -39,7 +39,7 @@
 // bit-reproducible).  No MFMA: the contraction is N x P -> P x P, P <= 5.
 //
 // Arithmetic: the distortion models are VALU-heavy enough to pull the chip's clock down (power), so every
-// flop taken out of the pixel body counts (scripts/valu_probe.hip: a packed op costs ~1.8x a scalar one, i.e. the unit
+// flop taken out of the pixel body counts (scripts/probes/valu_probe.hip: a packed op costs ~1.8x a scalar one, i.e. the unit
 // is FLOPs at 32 lanes/SIMD/cycle); the float4 path computes PIXEL PAIRS in packed fp32 (v_pk_fma_f32 /
 // v_pk_mul_f32 / v_pk_add_f32: two pixels per instruction) -- written explicitly on a 2-wide vector
 // type so the pairs live in adjacent registers straight out of the dwordx4 loads (LLVM's SLP

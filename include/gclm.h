@@ -88,7 +88,8 @@ typedef struct gclm_config {
     float lambda0;                   /* :150 */
     int32_t fix_lambda;              /* :151 */
     int32_t early_stop;              /* :152 (batch-global, :90-92,:619-625) */
-    float atol, rtol;                /* :153-154 */
+    float atol, rtol;                /* :153-154; the test |new - prev| <= atol + |rtol * prev| is evaluated in float32, as
+                                        torch.allclose does for float32 costs (the scalar tolerances do not promote) */
     int32_t use_spherical_manifold;  /* :155 */
     int32_t use_log_focal;           /* :156 */
     float up_loss_fn_scale;          /* :158 */

@@ -847,9 +847,12 @@ int lm_oracle_solve(const oracle_conf *cf, const oracle_data *d, float *cam_out 
                 real nl = lamb[b] * (new_cost[b] > prev_cost[b] ? R(10.0) : R(0.1));
                 lamb[b] = nl < R(1e-6) ? R(1e-6) : (nl > R(1e2) ? R(1e2) : nl);
             }
-            /* torch.allclose(new, prev): |new-prev| <= atol + rtol*|prev| */
-            double diff = fabs((double)new_cost[b] - (double)prev_cost[b]);
-            if (!(diff <= cf->atol + cf->rtol * fabs((double)prev_cost[b]))) all_close = 0;
+            /* torch.allclose(new, prev) (:90-92) evaluates |new - prev| <= atol + |rtol * prev| in the TENSORS' dtype (the
+             * tolerances are scalars and do not promote: ATen TensorCompare.cpp isclose): float32 in the reference */
+            volatile real scaled = (real)cf->rtol * prev_cost[b];      /* volatile: no fma contraction of the two roundings */
+            real diff = rfabs(new_cost[b] - prev_cost[b]);
+            real allowed = (real)cf->atol + rfabs(scaled);
+            if (!(diff <= allowed)) all_close = 0;
         }
         int brk = 0;
         if (all_close) {                                              /* :619-625 */

@@ -7,6 +7,6 @@ for rep in 1 2; do
     F="$A"; [ $V = B ] && F="$B"
     touch geocalib_amd/csrc/gclm_pass.hip
     make -C geocalib_amd/csrc PASS_FLAGS="$F" 2>&1 | grep -E "error|warning"
-    echo "== $V ($F) rep $rep"; python scripts/sweep_probe.py $MODELS $SIZES | tail -n +1
+    echo "== $V ($F) rep $rep"; python scripts/probes/sweep_probe.py $MODELS $SIZES | tail -n +1
   done
 done

@@ -7,6 +7,6 @@ for rep in $(seq 1 $REPS); do
   for V in A B; do
     L="$A"; [ $V = B ] && L="$B"
     echo "== $V ($L) rep $rep"
-    GCLM_LIB_PATH=$PWD/$L python scripts/sweep_probe.py $MODELS $SIZES
+    GCLM_LIB_PATH=$PWD/$L python scripts/probes/sweep_probe.py $MODELS $SIZES
   done
 done

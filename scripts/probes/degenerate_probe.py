@@ -1,6 +1,6 @@
 """GPU box: degenerate inputs must neither hang nor crash (zero confidences, NaNs, constant fields, tiny images)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from geocalib_amd import LMOptimizer
 from geocalib_amd.synth import synth_fields

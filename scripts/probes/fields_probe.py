@@ -1,8 +1,8 @@
 """GPU box: achieved HBM bandwidth of the two kernels either side of the LM path:
 gclm_pack_fields (CNN-head epilogue, reads 5 + writes 5 fp32 planes) and gclm_upsample_fields (_post_process bilinear).
-usage: python scripts/fields_probe.py [--json OUT]"""
+usage: python scripts/probes/fields_probe.py [--json OUT]"""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from geocalib_amd.fields import pack_fields, upsample_fields
 dev = torch.device("cuda:0")

@@ -1,6 +1,6 @@
 """Probe (GPU box): where the host-side microseconds of a single-image LMOptimizer.forward go (cProfile, 2000 calls)."""
 import cProfile, pstats, sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from geocalib_amd import LMOptimizer
 from geocalib_amd.synth import synth_fields

@@ -2,9 +2,10 @@
 All four tensors are views into ONE slab; tensor k starts `pad * k` bytes after the 2 MiB-aligned end of its predecessor.
 (Each tensor stays contiguous NCHW, as the boundary requires.)  usage: layout_probe.py [model] [B]"""
 import ctypes as C, sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from geocalib_amd import LMOptimizer, _lib
+LMOptimizer.overlap_streams = 1      # these probes time single launches (the library default would split a large batch over two streams)
 from geocalib_amd.synth import synth_fields
 lib = _lib.load(); dev = torch.device("cuda:0")
 model = sys.argv[1] if len(sys.argv) > 1 else "pinhole"

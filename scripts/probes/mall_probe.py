@@ -1,8 +1,9 @@
 """Probe: sweep time vs batch size (does a batch that fits the 256 MiB Infinity Cache sweep faster?)."""
 import ctypes as C, sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from geocalib_amd import LMOptimizer, _lib
+LMOptimizer.overlap_streams = 1      # these probes time single launches (the library default would split a large batch over two streams)
 from geocalib_amd.synth import synth_fields
 lib = _lib.load(); dev = torch.device("cuda:0")
 H, W = 480, 640

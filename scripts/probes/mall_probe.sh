@@ -9,7 +9,7 @@ for F in "" "-DGCLM_NT_LOADS=0" "-DGCLM_NOMATH=1" "-DGCLM_NOMATH=1 -DGCLM_NT_LOA
   touch geocalib_amd/csrc/gclm_pass.hip geocalib_amd/csrc/gclm_api.hip
   make -C geocalib_amd/csrc PASS_FLAGS="$F" CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast-honor-pragmas -Wall -Wno-unused-function $F" 2>&1 | grep -E "error|warning"
   echo "== flags [$F]"
-  GCLM_FUSED=0 python scripts/sweep_probe.py pinhole $SIZES
+  GCLM_FUSED=0 python scripts/probes/sweep_probe.py pinhole $SIZES
 done
 touch geocalib_amd/csrc/gclm_pass.hip geocalib_amd/csrc/gclm_api.hip
 make -C geocalib_amd/csrc 2>&1 | grep -E "error|warning"

@@ -3,9 +3,10 @@
 One batch of 1024 images solved (a) in one call on one stream, (b) as two halves on two streams of equal priority,
 (c) as two halves on a high- and a low-priority stream, (d) as four quarters on four streams.  Whole-solve wall time, median of 15."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from geocalib_amd import LMOptimizer
+LMOptimizer.overlap_streams = 1      # these probes time single launches (the library default would split a large batch over two streams)
 from geocalib_amd.synth import synth_fields
 dev = torch.device("cuda:0")
 model = sys.argv[1] if len(sys.argv) > 1 else "pinhole"

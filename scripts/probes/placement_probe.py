@@ -1,6 +1,6 @@
 """GPU box: does the physical placement of the inputs change the sweep time?  usage: placement_probe.py <prealloc GiB> [models]
 Allocates and frees <prealloc> GiB first (so that the inputs land elsewhere / in differently fragmented memory), then
-runs scripts/sweep_probe.py's measurement."""
+runs scripts/probes/sweep_probe.py's measurement."""
 import sys, os, runpy
 import torch
 gib = int(sys.argv[1])

@@ -2,9 +2,10 @@
 One process; several input sets kept alive side by side (different physical placements), each timed with the same
 handle; then single tensors of a set are re-allocated one at a time, and the handle (workspace) is re-created."""
 import ctypes as C, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from geocalib_amd import LMOptimizer, _lib
+LMOptimizer.overlap_streams = 1      # these probes time single launches (the library default would split a large batch over two streams)
 from geocalib_amd.synth import synth_fields
 lib, dev = _lib.load(), torch.device("cuda:0")
 model = sys.argv[1] if len(sys.argv) > 1 else "pinhole"

@@ -2,9 +2,10 @@
 (one slab = one hipMalloc: physically as contiguous as the driver makes it).  pads: bytes inserted between consecutive
 tensors (up_field | latitude_field | up_confidence | latitude_confidence)."""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from geocalib_amd import LMOptimizer, _lib
+LMOptimizer.overlap_streams = 1      # these probes time single launches (the library default would split a large batch over two streams)
 from geocalib_amd.synth import synth_fields
 lib, dev = _lib.load(), torch.device("cuda:0")
 B, H, W = 1024, 480, 640

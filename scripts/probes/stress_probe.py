@@ -2,6 +2,7 @@ import sys, os, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
 from geocalib_amd import LMOptimizer
+LMOptimizer.overlap_streams = 1      # these probes time single launches (the library default would split a large batch over two streams)
 from geocalib_amd.synth import synth_fields
 dev = torch.device("cuda:0")
 def run(model, B, H, W, steps=20):

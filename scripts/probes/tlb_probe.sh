@@ -1,12 +1,12 @@
 #!/bin/bash
 # GPU box: UTCL1 (per-CU address-translation cache) counters of the pinhole sweep in two physical placements of the inputs
-# (fresh process / a process that first allocated and freed 40 GiB).  usage: scripts/tlb_probe.sh [tag]
+# (fresh process / a process that first allocated and freed 40 GiB).  usage: scripts/probes/tlb_probe.sh [tag]
 TAG=${1:-tlb}; REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for G in 0 40; do
   for SET in "TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_MISS_UNDER_MISS_sum" "TCP_UTCL1_STALL_UTCL2_REQ_OUT_OF_CREDITS_sum TCP_UTCL1_THRASHING_STALL_sum TCP_UTCL1_STALL_INFLIGHT_MAX_sum GRBM_UTCL2_BUSY"; do
     N=$(echo $SET | cut -c11-20)
-    rocprofv3 --pmc $SET --output-format csv -d $OUT/p${G}_$N -o pmc -- python $REPO/scripts/placement_probe.py $G pinhole 1024 > $OUT/p${G}_$N.log 2>&1
+    rocprofv3 --pmc $SET --output-format csv -d $OUT/p${G}_$N -o pmc -- python $REPO/scripts/probes/placement_probe.py $G pinhole 1024 > $OUT/p${G}_$N.log 2>&1
     grep "sweep" $OUT/p${G}_$N.log | head -1
   done
 done

@@ -1,5 +1,5 @@
 // Microbenchmark (GPU box): issue cost of the VALU instructions the sweep kernel is made of, on gfx950.
-//   hipcc --offload-arch=gfx950 -O3 scripts/valu_probe.hip -o /tmp/valu_probe && /tmp/valu_probe
+//   hipcc --offload-arch=gfx950 -O3 scripts/probes/valu_probe.hip -o /tmp/valu_probe && /tmp/valu_probe
 // Every wave runs ITER x 32 independent instructions of one kind (8 accumulator chains); reports
 // shader cycles per instruction per SIMD at a given occupancy and the shader clock (s_memtime vs 100 MHz wall clock).
 #include <hip/hip_runtime.h>
