@@ -5,10 +5,12 @@
 // caller (file, environment, torch.distributed store ...).  Payloads are KBs: latency-bound, so both
 // collectives are issued once, in place, on the solve's stream.  The reference has no counterpart (its LM
 // is single-process; its only collectives are DDP training calls, siclib/train.py:275-337,491,537,678).
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 
@@ -21,6 +23,44 @@ struct gclm_comm {
 };
 
 namespace {
+// WHICH librccl this library talks to is decided here, not by link order: the RCCL the process has already loaded (a
+// torch process: torch/lib/librccl.so -- two RCCL instances in one process would each bring their own topology state and
+// kernels, and torch.distributed's communicators live in that one), otherwise ROCm's (/opt/rocm/lib/librccl.so.1).  The
+// library is therefore NOT linked against librccl; the seven entry points are resolved once, on first use.
+struct Rccl {
+    void* lib = nullptr;
+    std::string origin;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+const Rccl& rccl() {
+    std::call_once(g_rccl_once, [] {
+        Rccl& r = g_rccl;
+        const char* names[] = {"librccl.so.1", "librccl.so"};
+        for (const char* n : names)                                    // already in the process?
+            if (!r.lib && (r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) r.origin = std::string(n) + " (already loaded by the process)";
+        if (!r.lib && (r.lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL))) r.origin = "/opt/rocm/lib/librccl.so.1";
+        if (!r.lib && (r.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL))) r.origin = "librccl.so.1 (loader path)";
+        if (!r.lib) return;
+        r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(dlsym(r.lib, "ncclGetVersion"));
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
+        r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.lib, "ncclAllReduce"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+        r.ok = r.GetVersion && r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.AllReduce && r.GetErrorString;
+    });
+    return g_rccl;
+}
 thread_local std::string g_comm_error;
 int cfail(gclm_comm* c, int code, const char* what, const char* detail) {
     std::string m = std::string(what) + ": " + detail;
@@ -34,16 +74,17 @@ extern "C" {
 int gclm_comm_unique_id(void* id_out) {
     if (!id_out) return cfail(nullptr, -1, "gclm_comm_unique_id", "null argument");
     static_assert(sizeof(ncclUniqueId) == GCLM_COMM_ID_BYTES, "unique id size");
-    ncclResult_t r = ncclGetUniqueId(static_cast<ncclUniqueId*>(id_out));
-    return r == ncclSuccess ? 0 : cfail(nullptr, -20, "ncclGetUniqueId", ncclGetErrorString(r));
+    const Rccl& L = rccl();
+    if (!L.ok) return cfail(nullptr, -22, "gclm_comm_unique_id", "no usable librccl in the process or under /opt/rocm/lib");
+    ncclResult_t r = L.GetUniqueId(static_cast<ncclUniqueId*>(id_out));
+    return r == ncclSuccess ? 0 : cfail(nullptr, -20, "ncclGetUniqueId", L.GetErrorString(r));
 }
 
 int gclm_comm_versions(int* compiled, int* runtime) {
-    // Which librccl answers is decided by the dynamic loader: this library names /opt/rocm/lib/librccl.so.1 (RUNPATH), but a
-    // process that has already loaded another librccl with the same soname (a torch process: torch/lib/librccl.so) keeps
-    // that one.  Both are reported so that the caller can see which pair is running.
+    // the rccl.h this file was compiled against and the librccl rccl() bound (see there); 0 when none could be loaded
     int rt = 0;
-    if (ncclGetVersion(&rt) != ncclSuccess) rt = 0;
+    const Rccl& L = rccl();
+    if (!L.ok || L.GetVersion(&rt) != ncclSuccess) rt = 0;
     if (compiled) *compiled = NCCL_VERSION_CODE;
     if (runtime) *runtime = rt;
     return 0;
@@ -55,8 +96,10 @@ int gclm_comm_create(gclm_comm** out, const void* unique_id, int nranks, int ran
     *out = nullptr;
     // the three entry points used here (ncclCommInitRank / ncclAllGather / ncclAllReduce) are stable within a major
     // version; a librccl of another major version must not be driven through this header's declarations
+    const Rccl& L = rccl();
+    if (!L.ok) return cfail(nullptr, -22, "gclm_comm_create", "no usable librccl in the process or under /opt/rocm/lib");
     int rt = 0;
-    if (ncclGetVersion(&rt) != ncclSuccess || rt / 10000 != NCCL_VERSION_CODE / 10000) {
+    if (L.GetVersion(&rt) != ncclSuccess || rt / 10000 != NCCL_VERSION_CODE / 10000) {
         std::string m = "librccl at run time reports version " + std::to_string(rt) + ", this library was compiled against " +
                         std::to_string(NCCL_VERSION_CODE) + " (major versions differ)";
         return cfail(nullptr, -21, "gclm_comm_create", m.c_str());
@@ -67,9 +110,9 @@ int gclm_comm_create(gclm_comm** out, const void* unique_id, int nranks, int ran
     c->nranks = nranks; c->rank = rank; c->device = device;
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof(id));
-    ncclResult_t r = ncclCommInitRank(&c->comm, nranks, id, rank);
+    ncclResult_t r = L.CommInitRank(&c->comm, nranks, id, rank);
     if (r != ncclSuccess) {
-        cfail(nullptr, -20, "ncclCommInitRank", ncclGetErrorString(r));
+        cfail(nullptr, -20, "ncclCommInitRank", L.GetErrorString(r));
         delete c;
         return -20;
     }
@@ -79,7 +122,7 @@ int gclm_comm_create(gclm_comm** out, const void* unique_id, int nranks, int ran
 
 int gclm_comm_destroy(gclm_comm* c) {
     if (!c) return 0;
-    if (c->comm) ncclCommDestroy(c->comm);
+    if (c->comm) rccl().CommDestroy(c->comm);
     delete c;
     return 0;
 }
@@ -89,20 +132,20 @@ const char* gclm_comm_last_error(const gclm_comm* c) { return c ? c->err.c_str()
 int gclm_comm_all_gather(gclm_comm* c, const float* d_send, float* d_recv, size_t count_per_rank, void* stream) {
     if (c && count_per_rank == 0) return 0;        // every rank passes the same count: nothing to exchange anywhere
     if (!c || !d_send || !d_recv) return cfail(c, -1, "gclm_comm_all_gather", "null argument");
-    ncclResult_t r = ncclAllGather(d_send, d_recv, count_per_rank, ncclFloat, c->comm, static_cast<hipStream_t>(stream));
-    return r == ncclSuccess ? 0 : cfail(c, -20, "ncclAllGather", ncclGetErrorString(r));
+    ncclResult_t r = rccl().AllGather(d_send, d_recv, count_per_rank, ncclFloat, c->comm, static_cast<hipStream_t>(stream));
+    return r == ncclSuccess ? 0 : cfail(c, -20, "ncclAllGather", rccl().GetErrorString(r));
 }
 
 int gclm_comm_all_reduce_sum(gclm_comm* c, float* d_buf, size_t count, void* stream) {
     if (!c || !d_buf) return cfail(c, -1, "gclm_comm_all_reduce_sum", "null argument");
-    ncclResult_t r = ncclAllReduce(d_buf, d_buf, count, ncclFloat, ncclSum, c->comm, static_cast<hipStream_t>(stream));
-    return r == ncclSuccess ? 0 : cfail(c, -20, "ncclAllReduce", ncclGetErrorString(r));
+    ncclResult_t r = rccl().AllReduce(d_buf, d_buf, count, ncclFloat, ncclSum, c->comm, static_cast<hipStream_t>(stream));
+    return r == ncclSuccess ? 0 : cfail(c, -20, "ncclAllReduce", rccl().GetErrorString(r));
 }
 
 int gclm_comm_all_reduce_sum_i32(gclm_comm* c, int32_t* d_buf, size_t count, void* stream) {
     if (!c || !d_buf) return cfail(c, -1, "gclm_comm_all_reduce_sum_i32", "null argument");
-    ncclResult_t r = ncclAllReduce(d_buf, d_buf, count, ncclInt32, ncclSum, c->comm, static_cast<hipStream_t>(stream));
-    return r == ncclSuccess ? 0 : cfail(c, -20, "ncclAllReduce", ncclGetErrorString(r));
+    ncclResult_t r = rccl().AllReduce(d_buf, d_buf, count, ncclInt32, ncclSum, c->comm, static_cast<hipStream_t>(stream));
+    return r == ncclSuccess ? 0 : cfail(c, -20, "ncclAllReduce", rccl().GetErrorString(r));
 }
 
 }  // extern "C"

@@ -291,9 +291,11 @@ int gclm_comm_destroy(gclm_comm* c);
 /* Message of the last failing call on this communicator; c == NULL: of the last failing gclm_comm_unique_id /
  * gclm_comm_create of the CALLING THREAD (thread-local, as gclm_last_error(NULL)). */
 const char* gclm_comm_last_error(const gclm_comm* c);
-/* NCCL_VERSION_CODE of the rccl.h this library was compiled against and ncclGetVersion() of the librccl the dynamic
- * loader actually bound (a process that loaded another librccl.so.1 first -- torch ships its own -- keeps that one).
- * gclm_comm_create refuses (-21) a run-time library of another MAJOR version. */
+/* NCCL_VERSION_CODE of the rccl.h this library was compiled against and ncclGetVersion() of the librccl it bound at
+ * run time.  The library is not LINKED against librccl: on first use it takes the RCCL the process has already loaded
+ * (a torch process: torch's own librccl.so, the one torch.distributed's communicators live in), otherwise
+ * /opt/rocm/lib/librccl.so.1.  gclm_comm_create refuses (-21) a run-time library of another MAJOR version, and every
+ * gclm_comm_* entry point fails with -22 when no librccl can be loaded at all. */
 int gclm_comm_versions(int* compiled, int* runtime);
 int gclm_comm_all_gather(gclm_comm* c, const float* d_send, float* d_recv, size_t count_per_rank, void* stream);
 int gclm_comm_all_reduce_sum(gclm_comm* c, float* d_buf, size_t count, void* stream);

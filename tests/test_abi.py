@@ -95,6 +95,18 @@ def test_create_rejects_a_stale_caller():
     assert lib.gclm_create(C.byref(h), C.byref(zero)) == -5
 
 
+def test_rccl_is_bound_at_run_time_not_at_link_time():
+    """libgeocalib_hip.so is not linked against librccl: which RCCL it talks to is decided on first use (the one the process
+    already holds -- torch's -- else ROCm's), so two RCCL instances never meet in one process by an accident of load order."""
+    out = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "librccl" not in out, out
+    lib = _lib.load()
+    comp, run = C.c_int(0), C.c_int(0)
+    assert lib.gclm_comm_versions(C.byref(comp), C.byref(run)) == 0
+    assert comp.value >= 22000                       # NCCL_VERSION_CODE of the rccl.h of the build
+    assert run.value == 0 or run.value // 10000 == comp.value // 10000     # 0: no librccl on this box at all
+
+
 def test_no_cpu_fallback():
     """Without a HIP device the product path must refuse to run (and say why), never fall back."""
     import torch
