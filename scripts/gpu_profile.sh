@@ -18,16 +18,17 @@ python $REPO/bench.py --steps 10 --warmup 2 --camera-model $MODEL $EXTRA > $OUT/
 tail -c 2500 $OUT/bench_$NAME.json
 echo "== kernel trace $NAME"
 # the SAME command as the bench line (steps, warm-up, repeats), so that the two sweep averages are comparable: a short run
-# sweeps 2-3 % faster than a sustained one (power / clocks)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$NAME -o kt -- python $REPO/bench.py --steps 10 --warmup 2 --camera-model $MODEL $EXTRA --cpu-sample 0 > $OUT/kt_$NAME.log 2>&1
+# sweeps 2-3 % faster than a sustained one (power / clocks); without the line's extra passes (`secondary`, `overlap`), whose
+# launches would be averaged into the same kernel names
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$NAME -o kt -- python $REPO/bench.py --steps 10 --warmup 2 --camera-model $MODEL $EXTRA --cpu-sample 0 --no-secondary --no-overlap > $OUT/kt_$NAME.log 2>&1
 # the traced process prints its own bench line: its HIP-event sweep average and rocprofv3's come from the SAME launches
 grep -h "^{" $OUT/kt_$NAME.log | tail -1 > $OUT/bench_traced_$NAME.json
 find $OUT/kt_$NAME -name "*kernel_stats.csv" | head -1 | xargs -r head -8
 if [ "$PMC" = "1" ]; then
 echo "== pmc FETCH_SIZE"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$NAME -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --repeats 1 --cpu-sample 0 --no-timing --camera-model $MODEL $EXTRA > $OUT/pmc_fetch_$NAME.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$NAME -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --repeats 1 --cpu-sample 0 --no-timing --no-secondary --no-overlap --camera-model $MODEL $EXTRA > $OUT/pmc_fetch_$NAME.log 2>&1
 echo "== pmc WRITE_SIZE"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$NAME -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --repeats 1 --cpu-sample 0 --no-timing --camera-model $MODEL $EXTRA > $OUT/pmc_write_$NAME.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$NAME -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --repeats 1 --cpu-sample 0 --no-timing --no-secondary --no-overlap --camera-model $MODEL $EXTRA > $OUT/pmc_write_$NAME.log 2>&1
 python - <<PY
 import csv, glob, json, collections
 out = {}

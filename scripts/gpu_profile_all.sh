@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call that collects the round's evidence (bench lines, rocprofv3 kernel stats, HBM and SQ PMC passes, latency):
 #   gpurun --timeout 1500 -- 'scripts/gpu_profile_all.sh r03'        then copy the summaries: scripts/keep_profiles.py r03
-TAG=${1:-r03}
+TAG=${1:-r04}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $REPO
 S=scripts/gpu_profile.sh
@@ -18,4 +18,5 @@ scripts/pmc_sq.sh $TAG radial radial_B1024
 scripts/pmc_sq.sh $TAG simple_divisional simple_divisional_B1024
 scripts/rccl_1rank.sh $TAG
 python scripts/latency_probe.py --json gpurun_out/$TAG/latency.json
+python scripts/paced_probe.py --json gpurun_out/$TAG/paced.json
 du -sh gpurun_out/$TAG

@@ -2,7 +2,7 @@
 usage: python scripts/keep_profiles.py <tag>"""
 import glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
 kept = []
 for f in sorted(glob.glob(os.path.join(src, "bench_*.json"))):
@@ -29,6 +29,8 @@ for f in sorted(glob.glob(os.path.join(src, "pmc_sq_summary_*.json"))):
     shutil.copy(f, os.path.join(dst, f"{tag}_pmc_sq_{name}.json")); kept.append(f"{tag}_pmc_sq_{name}.json")
 for extra in glob.glob(os.path.join(src, "power_*.json")) + glob.glob(os.path.join(src, "ab_*.log")):
     shutil.copy(extra, os.path.join(dst, f"{tag}_{os.path.basename(extra)}")); kept.append(f"{tag}_{os.path.basename(extra)}")
+if os.path.exists(os.path.join(src, "paced.json")):
+    shutil.copy(os.path.join(src, "paced.json"), os.path.join(dst, f"{tag}_paced.json")); kept.append(f"{tag}_paced.json")
 if os.path.exists(os.path.join(src, "latency.json")):
     shutil.copy(os.path.join(src, "latency.json"), os.path.join(dst, f"{tag}_latency.json")); kept.append(f"{tag}_latency.json")
 # HBM traffic table read by bench.py (roofline.traffic): FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, KB -> bytes

@@ -5,7 +5,7 @@ shift 3 2>/dev/null || shift $#
 EXTRA="$*"
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$REPO/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python $REPO/bench.py --steps 1 --warmup 1 --repeats 1 --cpu-sample 0 --no-timing --camera-model $MODEL $EXTRA"
+B="python $REPO/bench.py --steps 1 --warmup 1 --repeats 1 --cpu-sample 0 --no-timing --no-secondary --no-overlap --camera-model $MODEL $EXTRA"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq_$NAME -o pmc -- $B > $OUT/pmc_sq_$NAME.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_RD SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_THREAD_CYCLES_VALU SQ_INST_LEVEL_VMEM --output-format csv -d $OUT/pmc_sq2_$NAME -o pmc -- $B > $OUT/pmc_sq2_$NAME.log 2>&1
 python - <<PY
