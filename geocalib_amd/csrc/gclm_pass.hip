@@ -666,15 +666,23 @@ __device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& 
             const F tr2 = DIST ? R.tau * r2 : r2;
             const F nn = DIST ? vfma(R.tau, tr2, vsplat(u, 1.0f)) : r2 + 1.0f;
             const F rnn = vrsq(nn);
-            const F trn = DIST ? R.tau * rnn : rnn;
             const F guv = vfma(u, vsplat(u, P.ga), vsplat(u, v * P.gb));
-            const F s_ = vfma(trn, guv, rnn * P.gc);
+            const F uT0 = vfma(u, vsplat(u, P.T00), vsplat(u, v * P.T10)), uT1 = vfma(u, vsplat(u, P.T01), vsplat(u, v * P.T11));
+            F s_, l[PN];
+            [[maybe_unused]] F trn = rnn;
+            if constexpr (DIST && LOGF && GCLM_RAY_FACTORED) {       // ray . x = rnn (tau (x_xy.uv) + x_z), see the fast body
+                s_ = vfma(R.tau, guv, vsplat(u, P.gc)) * rnn;
+                l[0] = vfma(R.tau, uT0, vsplat(u, P.T20)) * rnn;
+                l[1] = vfma(R.tau, uT1, vsplat(u, P.T21)) * rnn;
+            } else {
+                trn = DIST ? R.tau * rnn : rnn;
+                s_ = vfma(trn, guv, rnn * P.gc);
+                l[0] = vfma(trn, uT0, rnn * P.T20);
+                l[1] = vfma(trn, uT1, rnn * P.T21);
+            }
             const F sc = vclamp(s_, -1.0f + 1e-6f, 1.0f - 1e-6f);
             const F rl = slat - sc;                          // lm_optimizer.py:262,270-271 (slat = sin(latitude_field))
             const F wgt = huber_accumulate(rl * rl, hk.inv_a2l, cl, acc[A_CL]);
-            F l[PN];
-            l[0] = vfma(trn, vfma(u, vsplat(u, P.T00), vsplat(u, v * P.T10)), rnn * P.T20);
-            l[1] = vfma(trn, vfma(u, vsplat(u, P.T01), vsplat(u, v * P.T11)), rnn * P.T21);
             // ds/df = tau (h.w) + 2 tau1 (uv.w)(h.uv),  ds/dk_j = (dtau/dk_j)(h.uv)   (perspective_fields.py:255-272)
             //   h.uv = rnn (g_xy.uv - s trn r2),   h.w = rnn (g_xy.w - s trn (uv.w))
             [[maybe_unused]] F hu = vsplat(u, 0.f);
