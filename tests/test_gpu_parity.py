@@ -1565,6 +1565,34 @@ def test_one_launch_per_step_equals_the_two_launch_sequence(dev, model):
                 assert np.array_equal(two[k], one[k], equal_nan=True), (model, B, H, W, extra, strip, k)
             stops.append((two["stop_at"][0], conf.get("num_steps", 30)))
     assert any(s < n for s, n in stops) and any(s == n for s, n in stops)     # stops before and at the last step both occurred
+    # The first launch of the one-launch-per-step path builds the initial estimate itself (round 4: no init_kernel launch):
+    # every source of that estimate -- priors, `scales`, siclib's heuristic (it reads three pixels of the fields), a
+    # caller-provided camera / gravity (gclm_solve) -- must give the two-launch path's bits
+    data, gt_cam, gt_grav = synth_device(model, 1, 240, 320, dev, seed=32)
+    variants = [({}, {"prior_focal": (gt_cam[:, 3] * 1.1).contiguous()}),
+                ({}, {"prior_gravity": torch.nn.functional.normalize(gt_grav + 0.05, dim=-1).contiguous()}),
+                ({}, {"scales": torch.tensor([0.8, 1.25], device=dev)}),
+                ({"init_conf": {"name": "heuristic"}}, {}),
+                ({"init_conf": {"name": "heuristic"}, "num_steps": 0}, {})]
+    for extra, more in variants:
+        conf, d = {"camera_model": model, **extra}, {**data, **more}
+        two, one = solve(conf, d, 0), solve(conf, d, 1)
+        for k in two:
+            assert np.array_equal(two[k], one[k], equal_nan=True), (model, extra, list(more), k)
+
+    def solve_from(conf, mode):                          # LMOptimizer.optimize -> gclm_solve: the caller's initial estimate
+        from geocalib_amd.lm_optimizer import get_trivial_estimation
+        opt = LMOptimizer(conf).eval()
+        h = opt._handle(dev)
+        _lib.check(lib.gclm_set_fused_steps(h.ptr, mode), h.ptr, "gclm_set_fused_steps")
+        opt.setup_optimization_and_priors(data, shared_intrinsics=False)
+        cam0, grav0 = get_trivial_estimation(data, opt.camera_model)
+        cam0 = cam0.__class__(cam0._data * torch.tensor([1, 1, 1.2, 1.2, 1, 1, 1, 1], device=dev))
+        cam, grav, info = opt.optimize(data, cam0, grav0)
+        torch.cuda.synchronize()
+        return cam._data.cpu().numpy(), grav._data.cpu().numpy(), info["final_cost"].cpu().numpy()
+    for a, b in zip(solve_from({"camera_model": model}, 0), solve_from({"camera_model": model}, 1)):
+        assert np.array_equal(a, b, equal_nan=True), model
     # where it is not valid (a batch with the batch-global early stop) the request is ignored, not an error
     data, _, _ = synth_device(model, 3, 64, 80, dev, seed=2)
     a, b = solve({"camera_model": model}, data, 0), solve({"camera_model": model}, data, 1)
