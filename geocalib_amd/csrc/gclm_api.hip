@@ -20,8 +20,10 @@
 using namespace gclm;
 
 #ifndef GCLM_FUSED_MAX_WORKGROUPS
-#define GCLM_FUSED_MAX_WORKGROUPS 512      // B * workgroups-per-image up to which an LM step is ONE launch (see use_fused):
-                                           // measured (profiles/r03_latency.json) -- B = 1: -14 %; B = 4: +-0; B >= 16: slower
+#define GCLM_FUSED_MAX_WORKGROUPS 768      // B * workgroups-per-image up to which an LM step is ONE launch (see use_fused):
+                                           // measured with round 4's prologue (profiles/r04_fused_threshold.log, 20 fixed steps) --
+                                           // 640x480 (150 workgroups per image): B = 2 -19 %, 4 -15 %, 6 +-0, 8 +6 %, 12 +15 %;
+                                           // 320x240 (38 per image): B = 2 ... 12 -20 ... -27 %
 #endif
 #ifndef GCLM_ISO_FINAL
 #define GCLM_ISO_FINAL 1      // A/B switch: 0 = the final sweep always takes the general focal column
