@@ -540,7 +540,7 @@ int gclm_solve(gclm_handle* h, const float* d_up, const float* d_lat, const floa
     InitArgs ia{};
     ia.cam = d_cam_io;
     ia.grav = d_grav_io;
-    if (!d_cam_io || !d_grav_io) return fail(h, -3, "gclm_solve: null camera / gravity pointer");
+    if (B != 0 && (!d_cam_io || !d_grav_io)) return fail(h, -3, "gclm_solve: null camera / gravity pointer");
     return run_solve(h, d_up, d_lat, d_up_conf, d_lat_conf, B, H, W, ia, d_cam_io, d_grav_io, d_info_out, stream);
 }
 

@@ -726,6 +726,8 @@ def test_sharded_early_stop_through_the_stop_communicator(dev):
         assert lib.gclm_set_stop_comm(h.ptr, c) == 0
         assert lib.gclm_calibrate(h.ptr, None, None, None, None, 0, 96, 128, None, None, None, None, 0, None, None, None,
                                   torch.cuda.current_stream(dev).cuda_stream) == 0, _lib.last_error(h.ptr)
+        assert lib.gclm_solve(h.ptr, None, None, None, None, 0, 96, 128, None, None, None,
+                              torch.cuda.current_stream(dev).cuda_stream) == 0, _lib.last_error(h.ptr)
     assert lib.gclm_set_stop_comm(h.ptr, None) == 0
     torch.cuda.synchronize()
     assert np.array_equal(to_np(opt(data))["camera"], whole["camera"])   # the handle is as good as before
