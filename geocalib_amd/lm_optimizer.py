@@ -92,6 +92,16 @@ def _unit_gravity(data: torch.Tensor) -> Gravity:
     return g
 
 
+def _raw_stream(device: torch.device) -> int:
+    """The current HIP stream of `device` as the integer the C ABI takes (torch.cuda.current_stream(...).cuda_stream builds a
+    Stream object first: 4.5 us per call on the single-image path)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    try:
+        return torch._C._cuda_getCurrentRawStream(idx)
+    except AttributeError:            # a torch without the private accessor
+        return torch.cuda.current_stream(device).cuda_stream
+
+
 def _dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
     if not t.is_cuda:
         raise RuntimeError(f"geocalib_amd: `{name}` must live on a HIP device (got {t.device}); "
@@ -340,7 +350,9 @@ class LMOptimizer(nn.Module):
 
     def _unpack_info(self, info: torch.Tensor, has_up: bool) -> Dict[str, torch.Tensor]:
         I = _lib.INFO
-        col = info.t()              # column k of the packed rows = col[k]: an integer select, the cheapest view there is
+        # column k of the packed rows, for the 15 scalar columns in ONE call (15 separate integer selects were 12 us of a
+        # 38 us host path; scripts/probes/host_overhead_probe.py)
+        col = info.t()[:15].unbind(0)
         out = {"stop_at": col[I["stop_at"]]}
         if has_up:
             out["initial_up_cost"] = col[I["initial_up_cost"]]
@@ -408,7 +420,7 @@ class LMOptimizer(nn.Module):
         if B > self._MAX_CALL:
             return self._calibrate_chunked(data, B)
         device = lat.device
-        stream = torch.cuda.current_stream(device).cuda_stream      # looked up once: the handle's key and the launch stream
+        stream = _raw_stream(device)      # looked up once: the handle's key and the launch stream
         h = self._handle(device, stream)
 
         def prior(key, shape):

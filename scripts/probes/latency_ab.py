@@ -3,7 +3,7 @@
 in the SAME gpurun call for a same-box A/B:
     for l in a.so b.so; do GCLM_LIB_PATH=$l python scripts/probes/latency_ab.py; done"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from geocalib_amd import LMOptimizer, _lib
 from geocalib_amd.synth import synth_fields

@@ -2,7 +2,7 @@
 of workgroup 0's stages in every launch, from a -DGCLM_TRACE=1 build (scripts/build_variants.sh trace="-DGCLM_TRACE=1").
     GCLM_LIB_PATH=$PWD/geocalib_amd/lib/variants/trace.so python scripts/probes/trace_probe.py [model]"""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from geocalib_amd import LMOptimizer, _lib
 from geocalib_amd.synth import synth_fields
