@@ -2,8 +2,8 @@
 //
 // A solve is 2*num_steps+4 asynchronous launches on the caller's stream and no host round trip (nor memset):
 //   init | { sweep(theta_i) ; update_i } x num_steps | prep_final ; sweep(theta_final, rpf) ; finalize
-// and num_steps+3 for a single image (one launch per LM step, use_fused):
-//   init | fused(step) x num_steps | fused(final) | finalize
+// and num_steps+2 for a single image (one launch per LM step, use_fused; the first launch builds theta_0 itself):
+//   fused(step) x num_steps | fused(final) | finalize
 // (the reference syncs twice per step: H,G -> CPU Cholesky -> device, and torch.allclose).
 #include <chrono>
 #include <cstdarg>
@@ -456,7 +456,7 @@ static int run_solve(gclm_handle* h, const float* d_up, const float* d_lat, cons
     const bool fused_path = use_fused(h, B, geo);
     if (!fused_path) GCLM_HIP(h, launch_init(c, ia, s));      // (the one-launch-per-step path builds theta_0 in its first launch)
     if (fused_path) {
-        // init | fused(step) x num_steps | fused(final) | finalize : num_steps + 3 launches, partial records double-buffered
+        // fused(step) x num_steps | fused(final) | finalize : num_steps + 2 launches, partial records double-buffered
         float* const part[2] = {c.partials, c.partials2};
         // Paced launches (single image with early stop): the launches after the stop are skipped on the device, but each
         // still costs its turn on the queue (2.3 us x 21 of a default-conf solve).  Launch k is therefore only issued

@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL == GCLM_RADIAL) ? GCLM_R
 // ONE launch per LM step for small batches (the interactive B = 1 case of the reference's demo, interactive_demo.py:403):
 // the per-image update of step k-1 -- reduction of that step's partial records, lambda rule, damped Cholesky, manifold
 // update (gclm_device.h: lm_step, the very function update_kernel runs) -- is done REDUNDANTLY in the prologue of every
-// workgroup of sweep k, so an LM step is one launch instead of two and the host issues num_steps + 3 launches instead
+// workgroup of sweep k, so an LM step is one launch instead of two and the host issues num_steps + 2 launches instead
 // of 2 num_steps + 4.  Every workgroup of an image computes the same bits (fixed reduction order); workgroup 0 of the
 // image commits the new state and the early-stop counter.  Partial records are double-buffered (launch k reads the
 // records of launch k-1 while it writes its own).  Early stop: this kernel is only used when the decision is local to

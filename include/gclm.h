@@ -318,14 +318,15 @@ int gclm_set_sweep_iters(gclm_handle* h, int iters);
 
 /* Small batches (the interactive single-image calibration of the reference's demo, interactive_demo.py:403) run ONE
  * launch per LM step: the per-image update of step k-1 is done in the prologue of every workgroup of sweep k
- * (num_steps + 3 launches per solve instead of 2 num_steps + 4; results bit-identical to the two-launch sequence).
+ * (num_steps + 2 launches per solve instead of 2 num_steps + 4 -- the first launch also builds the initial estimate; results
+ * bit-identical to the two-launch sequence).
  * mode -1 (default): the library decides (few workgroups in flight); 0: never; 1: whenever it is valid (independent
  * intrinsics, 16-byte aligned fields of a width divisible by 4, and a single image or early_stop = 0 -- the
  * batch-global stop of lm_optimizer.py:619-625 is only decidable inside a launch when the batch is one image). */
 int gclm_set_fused_steps(gclm_handle* h, int mode);
 
 /* Single image with early_stop = 1 on the one-launch-per-step path: the launches after the stop return at their first
- * instruction, but each still takes its turn on the queue (21 of the 33 launches of a default-conf solve that stops at
+ * instruction, but each still takes its turn on the queue (21 of the 32 launches of a default-conf solve that stops at
  * step 9).  depth > 0 PACES the launches: launch k is issued once launch k - depth has reported to a word in
  * host-mapped memory, and none after the stop has been reported -- gclm_solve / gclm_calibrate then BLOCK the calling
  * thread for about the duration of the LM loop (the results are still produced asynchronously on the stream).  For
