@@ -9,5 +9,6 @@ Public surface (mirrors the reference's geocalib package for this path):
 from .camera import BaseCamera, Pinhole, Radial, SimpleDivisional, SimpleRadial, camera_models  # noqa: F401
 from .gravity import Gravity  # noqa: F401
 from .lm_optimizer import LMOptimizer, get_trivial_estimation  # noqa: F401
+from .extractor import GeoCalib  # noqa: F401,E402
 
 __version__ = "0.1.0"

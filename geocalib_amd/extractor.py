@@ -48,6 +48,9 @@ class GeoCalib(nn.Module):
         self.field_model = field_model
         self.preprocess = preprocess
         self.optimizer = LMOptimizer({**optimizer_options})
+        self.optimizer.eval()              # the reference puts its model in eval mode at construction (extractor.py:43): a
+                                           # freshly built GeoCalib returns the uncertainties; .train() / .eval() on the wrapper
+                                           # propagate to the optimiser like to any child module
         self.optimizer.paced_launches = int(paced_launches)
 
     def _post_process(self, camera: BaseCamera, img_data: Dict[str, torch.Tensor], out: Dict[str, torch.Tensor]):
@@ -81,7 +84,6 @@ class GeoCalib(nn.Module):
             prior_values["prior_gravity"] = pg[None] if len(pg.shape) == 0 else pg
         self.optimizer.set_camera_model(camera_model)
         self.optimizer.shared_intrinsics = shared_intrinsics
-        self.optimizer.train(self.training)
         out = dict(self.field_model(img_data))
         out |= {k: img_data[k] for k in ("image", "scales") if k in img_data}
         out |= prior_values

@@ -977,8 +977,12 @@ def test_calibrate_front_end(dev):
         return {"up_field": up.to(dev), "latitude_field": lat.to(dev), "up_confidence": ones.to(dev),
                 "latitude_confidence": ones.to(dev)}
 
-    model = GeoCalib(field_model).eval()
+    model = GeoCalib(field_model)            # as constructed, like the reference (extractor.py:43 evals its model): uncertainties on
+    assert not model.optimizer.training
     res = model.calibrate(torch.rand(3, H0, W0, device=dev))
+    assert {"roll_uncertainty", "pitch_uncertainty", "gravity_uncertainty", "focal_uncertainty", "vfov_uncertainty"} <= set(res)
+    assert "covariance" not in model.train().calibrate(torch.rand(3, H0, W0, device=dev))     # .train() reaches the optimiser
+    model.eval()
     assert res["up_field"].shape == (1, 2, H0, W0) and res["latitude_confidence"].shape == (1, H0, W0)
     c = res["camera"]
     assert c.size[0].tolist() == pytest.approx([W0, H0], abs=1e-3)
