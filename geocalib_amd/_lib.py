@@ -92,6 +92,7 @@ _SIGNATURES = {
     "gclm_comm_all_reduce_sum": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "gclm_comm_all_reduce_sum_i32": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "gclm_set_stop_comm": (C.c_int, [_P, _P]),
+    "gclm_merge_stop_at": (C.c_int, [C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int), C.c_int, _P]),
     "gclm_set_sweep_iters": (C.c_int, [_P, C.c_int]),
     "gclm_set_fused_steps": (C.c_int, [_P, C.c_int]),
     "gclm_set_paced_launches": (C.c_int, [_P, C.c_int]),

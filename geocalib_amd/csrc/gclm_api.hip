@@ -367,6 +367,28 @@ int gclm_set_stop_comm(gclm_handle* h, gclm_comm* c) {
     return 0;
 }
 
+int gclm_merge_stop_at(gclm_handle* const* parts, float* const* d_info, const int* B, int n_parts, void* stream) {
+    if (!parts || !d_info || !B || n_parts < 1 || !parts[0]) return -1;
+    gclm_handle* h0 = parts[0];
+    if (n_parts > kMaxMergeParts) return fail(h0, -3, "gclm_merge_stop_at: %d parts, at most %d", n_parts, kMaxMergeParts);
+    MergeStopArgs a{};
+    a.n = n_parts;
+    a.num_steps = h0->cfg.num_steps;
+    for (int p = 0; p < n_parts; ++p) {
+        gclm_handle* h = parts[p];
+        if (!h || !h->ctx.ctrl || (B[p] > 0 && !d_info[p])) return fail(h0, -3, "gclm_merge_stop_at: part %d has not solved anything", p);
+        if (h->device != h0->device || h->cfg.num_steps != h0->cfg.num_steps || h->cfg.early_stop)
+            return fail(h0, -2, "gclm_merge_stop_at: the parts must share device and num_steps and run with early_stop = 0");
+        a.ctrl[p] = h->ctx.ctrl;
+        a.info[p] = d_info[p];
+        a.B[p] = B[p];
+    }
+    DeviceGuard guard(h0->device);
+    GCLM_HIP(h0, guard.status);
+    GCLM_HIP(h0, launch_merge_stop(a, static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
 int gclm_set_fused_steps(gclm_handle* h, int mode) {
     if (!h) return -1;
     if (mode < -1 || mode > 1) return fail(h, -3, "gclm_set_fused_steps: mode %d not in {-1, 0, 1}", mode);

@@ -152,6 +152,14 @@ constexpr unsigned kPacedEpochShift = 20, kPacedEpochMask = 0xfffu;
 constexpr int kPacedPatienceUs = 2000;    // host wait for one report before the rest of the solve is issued unpaced ...
 constexpr int kPacedCooldown = 64;        // ... and solves of that handle that then do not pace at all
 bool sweep_has_log_focal();               // gclm_pass.hip: false in a -DGCLM_LOGF=0 measurement build
+constexpr int kMaxMergeParts = 8;
+struct MergeStopArgs {          // gclm_merge_stop_at: parts of one batch solved by separate handles
+    const Ctrl* ctrl[kMaxMergeParts];
+    float* info[kMaxMergeParts];
+    int B[kMaxMergeParts];
+    int n, num_steps;
+};
+hipError_t launch_merge_stop(const MergeStopArgs& a, hipStream_t s);
 hipError_t launch_fused_step(int camera_model, const SweepArgs& a, const FusedArgs& f, hipStream_t s);
 hipError_t launch_init(const SolveCtx& c, const InitArgs& ia, hipStream_t s);
 hipError_t launch_update(const SolveCtx& c, int step, hipStream_t s);

@@ -786,6 +786,29 @@ hipError_t launch_finalize(const SolveCtx& c, float* d_cam, float* d_grav, float
     else GCLM_LR(finalize_kernel<4>, c.B, s, c, d_cam, d_grav, d_info);
     return hipGetLastError();
 }
+// Parts of ONE batch solved by separate handles (LMOptimizer.overlap_streams): infos["stop_at"] is a property of the
+// whole batch -- the first step after which EVERY image's cost was "close" (lm_optimizer.py:619-620) -- so it is
+// re-derived from the SUM of the parts' per-step counters and written into every row of every part.
+__global__ void merge_stop_kernel(MergeStopArgs a) {
+    __shared__ int stop;
+    if (threadIdx.x == 0) {
+        int s = a.num_steps;
+        for (int j = 1; j < a.num_steps; ++j) {
+            int moved = 0;
+            for (int p = 0; p < a.n; ++p) moved += a.ctrl[p]->notclose[j];
+            if (moved == 0) { s = j; break; }
+        }
+        stop = s;
+    }
+    __syncthreads();
+    const float v = (float)stop;
+    for (int p = 0; p < a.n; ++p)
+        for (int i = threadIdx.x; i < a.B[p]; i += blockDim.x) a.info[p][(size_t)i * GCLM_INFO_STRIDE + GCLM_INFO_STOP_AT] = v;
+}
+hipError_t launch_merge_stop(const MergeStopArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(merge_stop_kernel, dim3(1), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
 #define GCLM_LG(kernel, s, ...) hipLaunchKernelGGL(kernel, dim3(c.n_groups), dim3(kGroups * kSlots), 0, s, __VA_ARGS__)
 hipError_t launch_shared_reduce(const SolveCtx& c, int step, float* d_group_partials, hipStream_t s) {
     if (c.n_groups <= 0) return hipSuccess;

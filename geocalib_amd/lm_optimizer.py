@@ -496,6 +496,7 @@ class LMOptimizer(nn.Module):
         def part(t, lo, hi):
             return None if t is None else t[lo:hi]
 
+        handles = []
         for i in range(n):
             lo, hi = bounds[i], bounds[i + 1]
             s = streams[i]
@@ -508,7 +509,18 @@ class LMOptimizer(nn.Module):
                                     cam.data_ptr(), grav.data_ptr(), info.data_ptr(), s.cuda_stream)
             if rc != 0:
                 _lib.check(rc, h.ptr, "gclm_calibrate")
+            handles.append(h)
             cur.wait_event(s.record_event())                # join: whatever follows on the caller's stream sees the results
+        # infos["stop_at"] is ONE number for the whole batch (the first step after which every image's cost was close,
+        # lm_optimizer.py:619-620): re-derived from the sum of the parts' per-step counters, on the caller's stream
+        C = _lib.C
+        info = outs[2]
+        parts = (C.c_void_p * n)(*[h.ptr.value for h in handles])
+        infos = (C.c_void_p * n)(*[info[bounds[i]:bounds[i + 1]].data_ptr() for i in range(n)])
+        sizes = (C.c_int * n)(*[bounds[i + 1] - bounds[i] for i in range(n)])
+        rc = lib.gclm_merge_stop_at(parts, infos, sizes, n, cur.cuda_stream)
+        if rc != 0:
+            _lib.check(rc, handles[0].ptr, "gclm_merge_stop_at")
 
     # ------------------------------------------------------------------ kernel-level entry (tests, tools)
     def system(self, data: Dict[str, torch.Tensor], camera: BaseCamera, gravity: Gravity,

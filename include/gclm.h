@@ -34,7 +34,7 @@ extern "C" {
 /* ABI version: bumped whenever struct gclm_config or the export list changes (100 = round 1/2, 300 = round 3:
  * struct_size / abi_version / device moved into gclm_config, gclm_create lost its third argument, new entry points
  * gclm_set_sweep_iters, gclm_set_fused_steps, gclm_set_paced_launches, gclm_set_stop_comm, gclm_comm_all_reduce_sum_i32,
- * gclm_abi_config_size; 400 = round 4: gclm_comm_versions added, the NULL-handle error strings became thread-local, an
+ * gclm_abi_config_size; 400 = round 4: gclm_comm_versions and gclm_merge_stop_at added, the NULL-handle error strings became thread-local, an
  * empty batch (B = 0, NULL fields) is accepted by gclm_solve / gclm_calibrate).  gclm_create refuses a gclm_config whose first two fields do not
  * carry the library's own sizeof(gclm_config) and GCLM_VERSION, with a message naming both sides. */
 #define GCLM_VERSION 400
@@ -310,6 +310,14 @@ int gclm_comm_all_reduce_sum_i32(gclm_comm* c, int32_t* d_buf, size_t count, voi
  * Every rank must run the same num_steps.  NULL unsets it.  Without it a sharded solve must run with early_stop = 0.
  */
 int gclm_set_stop_comm(gclm_handle* h, gclm_comm* c);
+
+/* A batch of independent images solved as several PARTS by several handles (e.g. on several streams of one device, so
+ * that one part's update launches run under another part's sweep; early_stop = 0): every output of a part is what the
+ * single call would have produced for those images, except infos["stop_at"] -- the reference's "first step after which
+ * EVERY image's cost was close" (lm_optimizer.py:619-620) is one number for the whole batch.  Call this after all parts
+ * have finished (stream order is the caller's business): it re-derives stop_at from the SUM of the parts' per-step
+ * counters and writes it into every row of every part's info.  At most 8 parts, same device / num_steps. */
+int gclm_merge_stop_at(gclm_handle* const* parts, float* const* d_info, const int* B, int n_parts, void* stream);
 
 /* Tuning / test hook (no reference counterpart): loop iterations per workgroup of the sweep (how an image is cut
  * into partial records; only the summation order depends on it).  0 restores the built-in choice (20, fewer for

@@ -1716,6 +1716,16 @@ def test_overlap_streams_equals_the_single_call(dev, model):
     eight, opt8 = solve(fixed, data, 8)                                   # capped: 513 // 256 = 2 parts
     assert opt8._overlap_parts(B) == 2
     assert all(np.array_equal(one[k], eight[k], equal_nan=True) for k in one)
+    # infos["stop_at"] is one number for the WHOLE batch: with 20 steps the two halves become "close" at different steps
+    # (seed 2024: 13 / 14), and the overlapped solve must still report the single call's (gclm_merge_stop_at sums the parts'
+    # per-step counters)
+    d20, _, _ = synth_device(model, B, H, W, dev, seed=2024)
+    long = {"num_steps": 20, "early_stop": False}
+    o1, _ = solve(long, d20, 1)
+    o2, _ = solve(long, d20, 2)
+    assert 1 < o1["stop_at"][0] < 20 and len(set(o1["stop_at"].tolist())) == 1
+    for k in o1:
+        assert np.array_equal(o1[k], o2[k], equal_nan=True), (model, k)
     withp = {**data, "prior_focal": gt_cam[:, 3].contiguous()}
     p1, _ = solve(fixed, withp, 1)
     p2, _ = solve(fixed, withp, 2)
