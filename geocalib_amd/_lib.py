@@ -73,6 +73,8 @@ _SIGNATURES = {
     "gclm_shared_apply": (C.c_int, [_P, C.c_int, _P, _P]),
     "gclm_shared_finish": (C.c_int, [_P, _P, _P]),
     "gclm_upsample_fields": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "gclm_upsample_fields_multi": (C.c_int, [C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_int, _P]),
     "gclm_gradient_hessian": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "gclm_optimizer_step": (C.c_int, [_P, _P, _P, C.c_int, C.c_float, C.c_int, C.c_int, _P, _P, _P]),
     "gclm_residual_fields": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),

@@ -737,6 +737,19 @@ int gclm_upsample_fields(const float* d_src, int planes, int h, int w, int H, in
     return e == hipSuccess ? 0 : -10;
 }
 
+int gclm_upsample_fields_multi(const float* const* d_srcs, float* const* d_dsts, const int* planes, int n_tensors, int h, int w,
+                               int H, int W, void* stream) {
+    if (!d_srcs || !d_dsts || !planes || n_tensors < 1 || n_tensors > kMaxUpsampleTensors || h <= 0 || w <= 0 || H <= 0 || W <= 0)
+        return -1;
+    UpsampleMulti m{};
+    m.n = n_tensors;
+    for (int t = 0; t < n_tensors; ++t) {
+        if (planes[t] < 0 || (planes[t] > 0 && (!d_srcs[t] || !d_dsts[t]))) return -1;
+        m.src[t] = d_srcs[t]; m.dst[t] = d_dsts[t]; m.planes[t] = planes[t];
+    }
+    return launch_upsample_multi(m, h, w, H, W, static_cast<hipStream_t>(stream)) == hipSuccess ? 0 : -10;
+}
+
 int gclm_pack_fields(const float* d_up_raw, const float* d_up_logconf, const float* d_lat_raw,
                      const float* d_lat_logconf, int B, int H, int W, float* d_up, float* d_up_conf, float* d_lat,
                      float* d_lat_conf, void* stream) {

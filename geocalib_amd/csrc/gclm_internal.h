@@ -171,6 +171,14 @@ hipError_t launch_shared_step(const SolveCtx& c, int step, hipStream_t s);
 hipError_t launch_system_out(const SolveCtx& c, float* d_cost, float* d_grad, float* d_hess, hipStream_t s);
 hipError_t launch_pblock_from_params(const SolveCtx& c, const float* d_cam, const float* d_grav, int as_rpf, PBlock* out, hipStream_t s);
 hipError_t launch_upsample(const float* src, int planes, int h, int w, int H, int W, float* dst, hipStream_t s);
+constexpr int kMaxUpsampleTensors = 8;
+struct UpsampleMulti {          // gclm_upsample_fields_multi: several tensors of (h, w) planes in one launch
+    const float* src[kMaxUpsampleTensors];
+    float* dst[kMaxUpsampleTensors];
+    int planes[kMaxUpsampleTensors];
+    int n;
+};
+hipError_t launch_upsample_multi(const UpsampleMulti& m, int h, int w, int H, int W, hipStream_t s);
 hipError_t launch_pack_fields(const float* up_raw, const float* up_lc, const float* lat_raw, const float* lat_lc,
                               int B, int H, int W, bool vec4, float* up, float* upc, float* lat, float* latc,
                               hipStream_t s);

@@ -632,45 +632,46 @@ __global__ void pack_fields_kernel(const float* __restrict__ up_raw, const float
 // source taps per pixel are L1 / L2 hits (neighbouring threads share them).  32-bit index arithmetic, rows walked with an
 // incremental (row, unit) counter instead of a division per pixel.  VEC = 1: any width / alignment.
 template <int VEC>
-__global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __restrict__ src, int planes, int h, int w,
-                                                                  int H, int W, float* __restrict__ dst) {
+__device__ __forceinline__ void upsample_plane(const float* __restrict__ s, float* __restrict__ d, int h, int w, int H, int W) {
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
     const int Wu = W / VEC;                           // units per output row
     const unsigned units = (unsigned)H * (unsigned)Wu;
     const unsigned stride = gridDim.x * blockDim.x;
     const int dY = (int)(stride / (unsigned)Wu), dXu = (int)(stride - (unsigned)dY * (unsigned)Wu);
-    for (int p = blockIdx.y; p < planes; p += gridDim.y) {
-        const float* s = src + (size_t)p * h * w;
-        float* d = dst + (size_t)p * H * W;
-        unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
-        int Y = (int)(q / (unsigned)Wu), Xu = (int)(q - (unsigned)Y * (unsigned)Wu);
-        for (; q < units; q += stride) {
-            const float fy = fmaxf(((float)Y + 0.5f) * sy - 0.5f, 0.f);
-            const int y0 = min((int)fy, h - 1), y1 = min(y0 + 1, h - 1);
-            const float ly = fy - (float)y0;
-            const float* r0 = s + y0 * w;
-            const float* r1 = s + y1 * w;
-            float o[VEC];
+    unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
+    int Y = (int)(q / (unsigned)Wu), Xu = (int)(q - (unsigned)Y * (unsigned)Wu);
+    for (; q < units; q += stride) {
+        const float fy = fmaxf(((float)Y + 0.5f) * sy - 0.5f, 0.f);
+        const int y0 = min((int)fy, h - 1), y1 = min(y0 + 1, h - 1);
+        const float ly = fy - (float)y0;
+        const float* r0 = s + y0 * w;
+        const float* r1 = s + y1 * w;
+        float o[VEC];
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                const int X = Xu * VEC + k;
-                const float fx = fmaxf(((float)X + 0.5f) * sx - 0.5f, 0.f);
-                const int x0 = min((int)fx, w - 1), x1 = min(x0 + 1, w - 1);
-                const float lx = fx - (float)x0;
-                const float top = r0[x0] * (1.f - lx) + r0[x1] * lx;
-                const float bot = r1[x0] * (1.f - lx) + r1[x1] * lx;
-                o[k] = top * (1.f - ly) + bot * ly;
-            }
-            if constexpr (VEC == 4) {
-                typedef float v4 __attribute__((ext_vector_type(4)));
-                __builtin_nontemporal_store(v4{o[0], o[1], o[2], o[3]}, reinterpret_cast<v4*>(d + (size_t)Y * W + Xu * 4));
-            } else {
-                d[(size_t)Y * W + Xu] = o[0];
-            }
-            Y += dY; Xu += dXu;
-            if (Xu >= Wu) { Xu -= Wu; ++Y; }
+        for (int k = 0; k < VEC; ++k) {
+            const int X = Xu * VEC + k;
+            const float fx = fmaxf(((float)X + 0.5f) * sx - 0.5f, 0.f);
+            const int x0 = min((int)fx, w - 1), x1 = min(x0 + 1, w - 1);
+            const float lx = fx - (float)x0;
+            const float top = r0[x0] * (1.f - lx) + r0[x1] * lx;
+            const float bot = r1[x0] * (1.f - lx) + r1[x1] * lx;
+            o[k] = top * (1.f - ly) + bot * ly;
         }
+        if constexpr (VEC == 4) {
+            typedef float v4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(v4{o[0], o[1], o[2], o[3]}, reinterpret_cast<v4*>(d + (size_t)Y * W + Xu * 4));
+        } else {
+            d[(size_t)Y * W + Xu] = o[0];
+        }
+        Y += dY; Xu += dXu;
+        if (Xu >= Wu) { Xu -= Wu; ++Y; }
     }
+}
+template <int VEC>
+__global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __restrict__ src, int planes, int h, int w,
+                                                                  int H, int W, float* __restrict__ dst) {
+    for (int p = blockIdx.y; p < planes; p += gridDim.y)
+        upsample_plane<VEC>(src + (size_t)p * h * w, dst + (size_t)p * H * W, h, w, H, W);
 }
 
 // optimizer_step (lm_optimizer.py:109-137) as a batched device kernel: delta = (H + diag(clamp(lambda diag H, eps)))^-1 G
@@ -846,6 +847,31 @@ hipError_t launch_system_out(const SolveCtx& c, float* d_cost, float* d_grad, fl
 hipError_t launch_pblock_from_params(const SolveCtx& c, const float* d_cam, const float* d_grav, int as_rpf,
                                      PBlock* out, hipStream_t s) {
     GCLM_L(pblock_from_params_kernel, c.B, s, c, d_cam, d_grav, as_rpf, out);
+    return hipGetLastError();
+}
+// Several tensors of (h, w) planes in ONE launch (the four tensors _post_process resizes: up 2 planes per image, latitude,
+// two confidences): a single-image calibrate() pays one launch instead of four.  grid.y walks the planes of all tensors.
+template <int VEC>
+__global__ __launch_bounds__(256) void upsample_bilinear_multi_kernel(UpsampleMulti m, int h, int w, int H, int W) {
+    int p = blockIdx.y, t = 0;
+    while (t < m.n - 1 && p >= m.planes[t]) { p -= m.planes[t]; ++t; }
+    upsample_plane<VEC>(m.src[t] + (size_t)p * h * w, m.dst[t] + (size_t)p * H * W, h, w, H, W);
+}
+hipError_t launch_upsample_multi(const UpsampleMulti& m, int h, int w, int H, int W, hipStream_t s) {
+    int total = 0;
+    bool vec4 = W % 4 == 0;
+    for (int t = 0; t < m.n; ++t) {
+        total += m.planes[t];
+        vec4 = vec4 && (reinterpret_cast<uintptr_t>(m.dst[t]) & 15u) == 0 && ((size_t)H * W) % 4 == 0;
+    }
+    if (total == 0 || (size_t)H * W == 0) return hipSuccess;
+    if (total > 65535) return hipErrorInvalidValue;
+    const unsigned units = (unsigned)H * (unsigned)(vec4 ? W / 4 : W);
+    unsigned bx = (units + 256 * 4 - 1) / (256 * 4);
+    if (bx < 1) bx = 1;
+    const dim3 grid(bx, total), block(256);
+    if (vec4) hipLaunchKernelGGL(upsample_bilinear_multi_kernel<4>, grid, block, 0, s, m, h, w, H, W);
+    else hipLaunchKernelGGL(upsample_bilinear_multi_kernel<1>, grid, block, 0, s, m, h, w, H, W);
     return hipGetLastError();
 }
 hipError_t launch_upsample(const float* src, int planes, int h, int w, int H, int W, float* dst, hipStream_t s) {

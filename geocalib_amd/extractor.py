@@ -15,23 +15,36 @@ import torch.nn as nn
 from torch.nn.functional import interpolate
 
 from .camera import BaseCamera
-from .fields import upsample_fields
+from .fields import upsample_fields_multi
 from .lm_optimizer import LMOptimizer
+
+
+_PRE_CACHE: Dict[tuple, tuple] = {}     # (h, w, resize, edge, device, dtype) -> the bookkeeping tensors of default_preprocess
 
 
 def default_preprocess(img: torch.Tensor, resize: int = 320, edge_divisible_by: int = 32) -> Dict[str, torch.Tensor]:
     """Short side to `resize` px (antialiased bilinear), centre-crop to multiples of `edge_divisible_by`.
-    Same bookkeeping keys as the reference's ImagePreprocessor (geocalib/utils.py:68-160)."""
+    Same bookkeeping keys as the reference's ImagePreprocessor (geocalib/utils.py:68-160), plus `_host`: the same numbers
+    as Python floats (they only depend on the image SHAPE), which lets `_post_process` skip a device-to-host read and a
+    dozen tiny tensor kernels.  The bookkeeping tensors are cached per input shape (no host-to-device copy per call)."""
     h, w = img.shape[-2:]
     s = resize / min(h, w)
     nh, nw = int(round(h * s)), int(round(w * s))
     out = interpolate(img, size=(nh, nw), mode="bilinear", antialias=True, align_corners=False)
-    scales = torch.tensor([nw / w, nh / h], dtype=img.dtype, device=img.device)
     ch, cw = nh // edge_divisible_by * edge_divisible_by, nw // edge_divisible_by * edge_divisible_by
     top, left = (nh - ch) // 2, (nw - cw) // 2
     out = out[..., top: top + ch, left: left + cw]
-    crop_pad = torch.tensor([cw - nw, ch - nh], dtype=img.dtype, device=img.device)
-    return {"image": out, "scales": scales, "crop_pad": crop_pad}
+    key = (h, w, resize, edge_divisible_by, img.device, img.dtype)
+    cached = _PRE_CACHE.get(key)
+    if cached is None:
+        scales = torch.tensor([nw / w, nh / h], dtype=img.dtype, device=img.device)
+        crop_pad = torch.tensor([cw - nw, ch - nh], dtype=img.dtype, device=img.device)
+        if len(_PRE_CACHE) > 64:
+            _PRE_CACHE.clear()
+        cached = _PRE_CACHE[key] = (scales, crop_pad)
+    scales, crop_pad = cached
+    return {"image": out, "scales": scales, "crop_pad": crop_pad,
+            "_host": {"scales": (nw / w, nh / h), "crop_pad": (float(cw - nw), float(ch - nh)), "size": (int(w), int(h))}}
 
 
 class GeoCalib(nn.Module):
@@ -53,15 +66,42 @@ class GeoCalib(nn.Module):
                                            # propagate to the optimiser like to any child module
         self.optimizer.paced_launches = int(paced_launches)
 
+    _UNDO_CACHE: Dict[tuple, tuple] = {}
+
     def _post_process(self, camera: BaseCamera, img_data: Dict[str, torch.Tensor], out: Dict[str, torch.Tensor]):
-        """Undo scaling / cropping and bring the fields back to the input resolution."""
-        camera = camera.undo_scale_crop(img_data)
-        w, h = (int(v) for v in camera.size[0].round().tolist())
-        for k in ("latitude_field", "up_field", "up_confidence", "latitude_confidence"):
-            if k in out:      # bilinear, align_corners=False (extractor.py:60-63), one HIP launch per tensor
-                out[k] = upsample_fields(out[k], (h, w))
-        zero = camera.new_zeros(camera.f.shape[0])
-        out["focal_uncertainty"] = out.get("focal_uncertainty", zero) * (1.0 / img_data["scales"])[1]
+        """Undo scaling / cropping and bring the fields back to the input resolution (extractor.py:51-69).
+
+        With the host-side bookkeeping of `default_preprocess` (`img_data["_host"]`) this is two launches and no
+        device-to-host read: ONE fused multiply-add on the camera rows -- the operations of `crop(-crop_pad).scale(1/scales)`
+        in their order, so the same bits -- and ONE bilinear launch for all four tensors.  A caller's own preprocess
+        without `_host` takes the reference's route (`undo_scale_crop`, the size read back from the camera)."""
+        host = img_data.get("_host")
+        tensors = [k for k in ("latitude_field", "up_field", "up_confidence", "latitude_confidence") if k in out]
+        if host is not None and "crop_pad" in img_data:
+            dev = camera._data.device
+            key = (host["scales"], host["crop_pad"], dev)
+            cached = self._UNDO_CACHE.get(key)
+            if cached is None:
+                inv = 1.0 / torch.tensor(host["scales"], dtype=torch.float32)            # float32 like `1.0 / data["scales"]`
+                px, py = host["crop_pad"]
+                add = torch.tensor([-px, -py, 0.0, 0.0, -px / 2, -py / 2, 0.0, 0.0], dtype=torch.float32)
+                mul = torch.stack([inv[0], inv[1], inv[0], inv[1], inv[0], inv[1], inv.new_tensor(1.0), inv.new_tensor(1.0)])
+                if len(self._UNDO_CACHE) > 64:
+                    self._UNDO_CACHE.clear()
+                cached = self._UNDO_CACHE[key] = (add.to(dev), mul.to(dev), float(inv[1]))
+            add, mul, inv_sy = cached
+            camera = camera.__class__((camera._data + add) * mul)
+            w, h = host["size"]
+            zero_or_fu = out.get("focal_uncertainty")
+            out["focal_uncertainty"] = (camera.new_zeros(camera.f.shape[0]) if zero_or_fu is None else zero_or_fu) * inv_sy
+        else:
+            camera = camera.undo_scale_crop(img_data)
+            w, h = (int(v) for v in camera.size[0].round().tolist())
+            zero = camera.new_zeros(camera.f.shape[0])
+            out["focal_uncertainty"] = out.get("focal_uncertainty", zero) * (1.0 / img_data["scales"])[1]
+        if tensors:        # bilinear, align_corners=False (extractor.py:60-63): one HIP launch for all of them
+            for k, t in zip(tensors, upsample_fields_multi([out[k] for k in tensors], (h, w))):
+                out[k] = t
         return camera, out
 
     @torch.no_grad()

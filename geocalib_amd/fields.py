@@ -13,6 +13,7 @@ from typing import Dict, Optional
 import torch
 
 from . import _lib
+from .lm_optimizer import _raw_stream
 
 
 def pack_fields(up_raw: torch.Tensor, lat_raw: torch.Tensor, up_log_confidence: Optional[torch.Tensor] = None,
@@ -65,6 +66,33 @@ def upsample_fields(t: torch.Tensor, size) -> torch.Tensor:
     if rc != 0:
         raise _lib.GclmError(f"gclm_upsample_fields failed ({rc})")
     return dst
+
+
+def upsample_fields_multi(tensors, size):
+    """`upsample_fields` for several tensors of equal (h, w) in ONE launch (gclm_upsample_fields_multi): the outputs are views
+    of one allocation, each contiguous, with the leading shape of its source."""
+    H, W = int(size[0]), int(size[1])
+    srcs = []
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError("geocalib_amd.upsample_fields_multi needs HIP device tensors (no CPU fallback)")
+        srcs.append(t.detach().to(torch.float32).contiguous())
+    h, w = srcs[0].shape[-2:]
+    assert all(t.shape[-2:] == (h, w) and t.device == srcs[0].device for t in srcs) and 1 <= len(srcs) <= 8
+    planes = [t.numel() // (h * w) for t in srcs]
+    flat = srcs[0].new_empty((sum(planes), H, W))
+    outs, lo = [], 0
+    for t, n in zip(srcs, planes):
+        outs.append(flat[lo:lo + n].view(t.shape[:-2] + (H, W)))
+        lo += n
+    C = _lib.C
+    n = len(srcs)
+    rc = _lib.load().gclm_upsample_fields_multi((C.c_void_p * n)(*[t.data_ptr() for t in srcs]),
+                                                 (C.c_void_p * n)(*[o.data_ptr() for o in outs]), (C.c_int * n)(*planes), n, h, w,
+                                                 H, W, _raw_stream(srcs[0].device))
+    if rc != 0:
+        raise _lib.GclmError(f"gclm_upsample_fields_multi failed ({rc})")
+    return outs
 
 
 def fastest_placement(allocate, solve, tries: int = 3, keep_first: bool = False):

@@ -34,7 +34,7 @@ extern "C" {
 /* ABI version: bumped whenever struct gclm_config or the export list changes (100 = round 1/2, 300 = round 3:
  * struct_size / abi_version / device moved into gclm_config, gclm_create lost its third argument, new entry points
  * gclm_set_sweep_iters, gclm_set_fused_steps, gclm_set_paced_launches, gclm_set_stop_comm, gclm_comm_all_reduce_sum_i32,
- * gclm_abi_config_size; 400 = round 4: gclm_comm_versions and gclm_merge_stop_at added, the NULL-handle error strings became thread-local, an
+ * gclm_abi_config_size; 400 = round 4: gclm_comm_versions, gclm_merge_stop_at and gclm_upsample_fields_multi added, the NULL-handle error strings became thread-local, an
  * empty batch (B = 0, NULL fields) is accepted by gclm_solve / gclm_calibrate).  gclm_create refuses a gclm_config whose first two fields do not
  * carry the library's own sizeof(gclm_config) and GCLM_VERSION, with a message naming both sides. */
 #define GCLM_VERSION 400
@@ -208,6 +208,10 @@ int gclm_pack_fields(const float* d_up_raw, const float* d_up_logconf, const flo
  * contiguous (h, w) planes in d_src (e.g. B*2 for the up field); d_dst holds planes x (H, W).
  */
 int gclm_upsample_fields(const float* d_src, int planes, int h, int w, int H, int W, float* d_dst, void* stream);
+/* ... and the same for up to 8 tensors of (h, w) planes in ONE launch (the four tensors _post_process resizes: a
+ * single-image calibrate() pays one launch instead of four); at most 65 535 planes in total. */
+int gclm_upsample_fields_multi(const float* const* d_srcs, float* const* d_dsts, const int* planes, int n_tensors, int h, int w,
+                               int H, int W, void* stream);
 
 /*
  * LMOptimizer.calculate_gradient_and_hessian (geocalib/lm_optimizer.py:317-385) on materialised tensors:

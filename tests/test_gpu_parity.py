@@ -992,6 +992,34 @@ def test_calibrate_front_end(dev):
     assert res["covariance"].shape == (1, 3, 3) and res["focal_uncertainty"].shape == (1,)
 
 
+def test_post_process_fast_path_equals_the_reference_route(dev):
+    """GeoCalib._post_process with the host-side bookkeeping of default_preprocess (one fused multiply-add on the camera
+    rows, ONE bilinear launch for the four tensors, no device-to-host read) against the reference's route
+    (`undo_scale_crop`, size read back from the camera, one interpolate per tensor): same bits for the camera and the
+    focal uncertainty, F.interpolate's values for the fields; several images (shared intrinsics) as well."""
+    import torch.nn.functional as F
+    from geocalib_amd import GeoCalib, camera_models
+    from geocalib_amd.extractor import default_preprocess
+    for B, (H0, W0) in ((1, (768, 1024)), (3, (480, 700)), (1, (333, 517))):
+        img = torch.rand(B, 3, H0, W0, device=dev)
+        data = default_preprocess(img)
+        h, w = data["image"].shape[-2:]
+        cam = camera_models["simple_radial"](torch.tensor([[w, h, 300.0, 310.0, w / 2 + 1.5, h / 2 - 0.75, -0.1, -0.1]], device=dev).repeat(B, 1))
+        fields = {"up_field": torch.randn(B, 2, h, w, device=dev), "latitude_field": torch.randn(B, 1, h, w, device=dev),
+                  "up_confidence": torch.rand(B, h, w, device=dev), "latitude_confidence": torch.rand(B, h, w, device=dev),
+                  "focal_uncertainty": torch.rand(B, device=dev)}
+        model = GeoCalib(lambda d: {})
+        c1, o1 = model._post_process(cam, data, dict(fields))
+        c2, o2 = model._post_process(cam, {k: v for k, v in data.items() if k != "_host"}, dict(fields))
+        assert torch.equal(c1._data, c2._data) and torch.equal(o1["focal_uncertainty"], o2["focal_uncertainty"])
+        assert c1.size[0].tolist() == pytest.approx([W0, H0], abs=1e-3)
+        for k in ("up_field", "latitude_field", "up_confidence", "latitude_confidence"):
+            assert o1[k].shape == o2[k].shape == fields[k].shape[:-2] + (H0, W0) and torch.equal(o1[k], o2[k])
+            src = fields[k] if fields[k].dim() == 4 else fields[k][:, None]
+            ref = F.interpolate(src, size=(H0, W0), mode="bilinear", align_corners=False).reshape(o1[k].shape)
+            assert torch.allclose(o1[k], ref, atol=2e-6, rtol=1e-6), k
+
+
 def test_hip_matches_reference_shared_radial(dev):
     """Shared intrinsics with the 5-parameter radial model: 3x3 Schur complement vs the reference's dense solve."""
     g = np.load(os.path.join(GOLDEN, "golden_extra.npz"))
