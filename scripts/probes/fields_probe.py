@@ -42,6 +42,11 @@ for B, (h, w), (H, W) in ((256, (240, 320), (480, 640)), (64, (320, 480), (1080,
     byt = B * 5 * 4 * (h * w + H * W)
     rows.append({"kernel": "gclm_upsample_fields", "B": B, "src": [h, w], "dst": [H, W], "ms": round(ms, 4), "GB/s": round(byt / ms / 1e6, 1), "bytes": byt})
     print(rows[-1], flush=True)
+    dstbuf = torch.empty((B, 5, H, W), device=dev)
+    ms_f = timeit(lambda: dstbuf.fill_(1.0))
+    rows.append({"kernel": "torch fill_ of the output (pure write, for scale)", "B": B, "dst": [H, W], "ms": round(ms_f, 4), "GB/s": round(dstbuf.numel() * 4 / ms_f / 1e6, 1)})
+    print(rows[-1], flush=True)
+    del dstbuf
     ms_t = timeit(lambda: torch.nn.functional.interpolate(src, (H, W), mode="bilinear", align_corners=False), 5)
     rows.append({"kernel": "torch F.interpolate bilinear", "B": B, "src": [h, w], "dst": [H, W], "ms": round(ms_t, 4), "GB/s": round(byt / ms_t / 1e6, 1)})
     print(rows[-1], flush=True)
