@@ -680,6 +680,9 @@ __global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __r
 // are wave-uniform, and the horizontally interpolated values of a SOURCE row are kept in registers and reused by every
 // output row that taps it (a 2x upsampling taps each source row from ~4 output rows): ~4 gathers per store instead of 16.
 // Same formulas per output value as upsample_plane.
+#ifndef GCLM_UPSAMPLE_PLAIN_STORE
+#define GCLM_UPSAMPLE_PLAIN_STORE 0      // A/B switch
+#endif
 constexpr int kUpRows = 8;
 __device__ __forceinline__ void upsample_strip(const float* __restrict__ s, float* __restrict__ d, int h, int w, int H, int W,
                                                int Xu, int Y0) {
@@ -727,7 +730,11 @@ __device__ __forceinline__ void upsample_strip(const float* __restrict__ s, floa
             typedef float v4 __attribute__((ext_vector_type(4)));
             const v4 o = {ha[0] * (1.f - ly) + hb[0] * ly, ha[1] * (1.f - ly) + hb[1] * ly, ha[2] * (1.f - ly) + hb[2] * ly,
                           ha[3] * (1.f - ly) + hb[3] * ly};
+#if GCLM_UPSAMPLE_PLAIN_STORE
+            *reinterpret_cast<v4*>(d + (size_t)Y * W + Xu * 4) = o;
+#else
             __builtin_nontemporal_store(o, reinterpret_cast<v4*>(d + (size_t)Y * W + Xu * 4));
+#endif
         }
     }
 }
