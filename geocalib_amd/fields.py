@@ -106,7 +106,7 @@ def fastest_placement(allocate, solve, tries: int = 3, keep_first: bool = False)
         allocate() -> dict of device tensors (a candidate; all candidates are alive at the same time, hence on
                       different pages);   solve(fields) -> anything (one calibration of the candidate, e.g. an LMOptimizer)
 
-    Every candidate is solved twice (warm-up, then timed with HIP events on the current stream); returns
+    Every candidate is solved three times (warm-up, then the better of two timed with HIP events on the current stream); returns
     (fields_of_the_fastest, [milliseconds of every candidate]).  The others are dropped.  `keep_first`: a third value,
     the FIRST candidate's fields (what a caller who allocates once gets) -- measurement rigs report both.
 
@@ -120,12 +120,15 @@ def fastest_placement(allocate, solve, tries: int = 3, keep_first: bool = False)
     for _ in range(tries):
         f = allocate()
         solve(f)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        solve(f)
-        e1.record()
-        e1.synchronize()
+        best_ms = float("inf")
+        for _ in range(2):            # the better of two timed solves: the candidates differ by 1-4 %, one solve's jitter is ~0.5 %
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            solve(f)
+            e1.record()
+            e1.synchronize()
+            best_ms = min(best_ms, e0.elapsed_time(e1))
         cands.append(f)
-        times.append(e0.elapsed_time(e1))
+        times.append(best_ms)
     best = min(range(tries), key=times.__getitem__)
     return (cands[best], times, cands[0]) if keep_first else (cands[best], times)

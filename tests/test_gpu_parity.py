@@ -1694,7 +1694,7 @@ def test_paced_launches_change_how_many_launches_are_issued_and_nothing_else(dev
 
 @pytest.mark.gpu
 def test_fastest_placement_returns_one_of_its_candidates(dev):
-    """geocalib_amd.fields.fastest_placement: `tries` allocations alive side by side, each solved twice, the fastest kept;
+    """geocalib_amd.fields.fastest_placement: `tries` allocations alive side by side, each solved three times (warm-up + the better of two timed), the fastest kept;
     tries <= 1 allocates once and times nothing."""
     from geocalib_amd import LMOptimizer
     from geocalib_amd.fields import fastest_placement
