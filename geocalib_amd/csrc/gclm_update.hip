@@ -683,7 +683,11 @@ __global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __r
 #ifndef GCLM_UPSAMPLE_PLAIN_STORE
 #define GCLM_UPSAMPLE_PLAIN_STORE 0      // A/B switch
 #endif
+#ifndef GCLM_UPSAMPLE_EXPERIMENT
+#define GCLM_UPSAMPLE_EXPERIMENT 0
+#endif
 constexpr int kUpRows = 8;
+template <bool WIDE>
 __device__ __forceinline__ void upsample_strip(const float* __restrict__ s, float* __restrict__ d, int h, int w, int H, int W,
                                                int Xu, int Y0) {
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
@@ -698,10 +702,33 @@ __device__ __forceinline__ void upsample_strip(const float* __restrict__ s, floa
         x1[k] = min(x0[k] + 1, w - 1);
         lx[k] = fx - (float)x0[k];
     }
+    // WIDE (upsampling by >= 1.5, i.e. sx <= 2/3, and w >= 4): the eight taps of a lane's four pixels lie within FOUR
+    // consecutive source floats, so a source row costs ONE 16-byte load per lane (4-byte aligned) and eight register
+    // selects instead of eight dword gathers -- a stride-2 dword gather was measured at ~25 cycles of a CU's address
+    // unit apiece, and gathers and stores share that unit (no-gather build 0.30 ms + no-store build 0.32 ms = 0.63 ms).
+    const int xs = min(x0[0], w - 4);
+    int i0[4], i1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { i0[k] = x0[k] - xs; i1[k] = x1[k] - xs; }
+    auto pick = [](const float (&t)[4], int i) { return i == 0 ? t[0] : (i == 1 ? t[1] : (i == 2 ? t[2] : t[3])); };
     auto hrow = [&](int y, float (&o)[4]) {
         const float* r = s + (size_t)y * w;
+        if constexpr (WIDE) {
+            typedef float v4u __attribute__((ext_vector_type(4), aligned(4)));
+            const v4u q = *reinterpret_cast<const v4u*>(r + xs);
+            const float t[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = pick(t, i0[k]) * (1.f - lx[k]) + pick(t, i1[k]) * lx[k];
+            return;
+        }
+#if GCLM_UPSAMPLE_EXPERIMENT == 1      // measurement only: no gathers (what do index math + stores cost?)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (float)(y + x0[k]) * (1.f - lx[k]) + (float)x1[k] * lx[k];
+        (void)r;
+#else
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[k] = r[x0[k]] * (1.f - lx[k]) + r[x1[k]] * lx[k];
+#endif
     };
     int ya = -1, yb = -1;
     float ha[4] = {0.f, 0.f, 0.f, 0.f}, hb[4] = {0.f, 0.f, 0.f, 0.f};
@@ -726,7 +753,11 @@ __device__ __forceinline__ void upsample_strip(const float* __restrict__ s, floa
             }
             yb = y1;
         }
+#if GCLM_UPSAMPLE_EXPERIMENT == 2          // measurement only: no stores (what do the gathers + math cost?)
+        if (live && ha[0] * (1.f - ly) + hb[0] * ly == 1.2345e30f) {
+#else
         if (live) {
+#endif
             typedef float v4 __attribute__((ext_vector_type(4)));
             const v4 o = {ha[0] * (1.f - ly) + hb[0] * ly, ha[1] * (1.f - ly) + hb[1] * ly, ha[2] * (1.f - ly) + hb[2] * ly,
                           ha[3] * (1.f - ly) + hb[3] * ly};
@@ -739,12 +770,15 @@ __device__ __forceinline__ void upsample_strip(const float* __restrict__ s, floa
     }
 }
 // grid = (strips of 64 units, blocks of 4 waves x kUpRows rows, planes); one wave per (strip, row group)
+template <bool WIDE>
 __global__ __launch_bounds__(256) void upsample_tiled_kernel(const float* __restrict__ src, int planes, int h, int w, int H, int W,
                                                              float* __restrict__ dst) {
     const int Xu = blockIdx.x * 64 + (threadIdx.x & 63), Y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * kUpRows;
     for (int p = blockIdx.z; p < planes; p += gridDim.z)
-        upsample_strip(src + (size_t)p * h * w, dst + (size_t)p * H * W, h, w, H, W, Xu, Y0);
+        upsample_strip<WIDE>(src + (size_t)p * h * w, dst + (size_t)p * H * W, h, w, H, W, Xu, Y0);
 }
+// the four-float window holds every tap of four adjacent output pixels: x0[3] <= x0[0] + ceil(3 sx) <= x0[0] + 2
+__host__ inline bool upsample_wide_ok(int w, int W) { return w >= 4 && 3LL * w <= 2LL * W; }
 
 // optimizer_step (lm_optimizer.py:109-137) as a batched device kernel: delta = (H + diag(clamp(lambda diag H, eps)))^-1 G
 // by an fp32 Cholesky per system (the reference copies H, G to the CPU for this, twice per LM step).  A system
@@ -928,11 +962,12 @@ __global__ __launch_bounds__(256) void upsample_scalar_multi_kernel(UpsampleMult
     while (t < m.n - 1 && p >= m.planes[t]) { p -= m.planes[t]; ++t; }
     upsample_plane<1>(m.src[t] + (size_t)p * h * w, m.dst[t] + (size_t)p * H * W, h, w, H, W);
 }
+template <bool WIDE>
 __global__ __launch_bounds__(256) void upsample_tiled_multi_kernel(UpsampleMulti m, int h, int w, int H, int W) {
     int p = blockIdx.z, t = 0;
     while (t < m.n - 1 && p >= m.planes[t]) { p -= m.planes[t]; ++t; }
     const int Xu = blockIdx.x * 64 + (threadIdx.x & 63), Y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * kUpRows;
-    upsample_strip(m.src[t] + (size_t)p * h * w, m.dst[t] + (size_t)p * H * W, h, w, H, W, Xu, Y0);
+    upsample_strip<WIDE>(m.src[t] + (size_t)p * h * w, m.dst[t] + (size_t)p * H * W, h, w, H, W, Xu, Y0);
 }
 hipError_t launch_upsample_multi(const UpsampleMulti& m, int h, int w, int H, int W, hipStream_t s) {
     int total = 0;
@@ -945,7 +980,8 @@ hipError_t launch_upsample_multi(const UpsampleMulti& m, int h, int w, int H, in
     if (total > 65535) return hipErrorInvalidValue;
     if (vec4) {
         const dim3 grid((W / 4 + 63) / 64, (H + 4 * kUpRows - 1) / (4 * kUpRows), total);
-        hipLaunchKernelGGL(upsample_tiled_multi_kernel, grid, dim3(256), 0, s, m, h, w, H, W);
+        if (upsample_wide_ok(w, W)) hipLaunchKernelGGL(upsample_tiled_multi_kernel<true>, grid, dim3(256), 0, s, m, h, w, H, W);
+        else hipLaunchKernelGGL(upsample_tiled_multi_kernel<false>, grid, dim3(256), 0, s, m, h, w, H, W);
     } else {
         unsigned bx = ((unsigned)H * (unsigned)W + 256 * 4 - 1) / (256 * 4);
         hipLaunchKernelGGL(upsample_scalar_multi_kernel, dim3(bx < 1 ? 1 : bx, total), dim3(256), 0, s, m, h, w, H, W);
@@ -962,7 +998,8 @@ hipError_t launch_upsample(const float* src, int planes, int h, int w, int H, in
     const dim3 grid(bx, planes < 65535 ? planes : 65535), block(256);
     if (vec4) {
         const dim3 tgrid((W / 4 + 63) / 64, (H + 4 * kUpRows - 1) / (4 * kUpRows), planes < 65535 ? planes : 65535);
-        hipLaunchKernelGGL(upsample_tiled_kernel, tgrid, block, 0, s, src, planes, h, w, H, W, dst);
+        if (upsample_wide_ok(w, W)) hipLaunchKernelGGL(upsample_tiled_kernel<true>, tgrid, block, 0, s, src, planes, h, w, H, W, dst);
+        else hipLaunchKernelGGL(upsample_tiled_kernel<false>, tgrid, block, 0, s, src, planes, h, w, H, W, dst);
     } else {
         hipLaunchKernelGGL(upsample_bilinear_kernel<1>, grid, block, 0, s, src, planes, h, w, H, W, dst);
     }

@@ -947,7 +947,13 @@ def test_randomised_configurations_against_oracle(dev, oracle):
     assert med[0] < 2e-5 and med[1] < 2e-5 and med[3] < 2e-5, med
 
 
-@pytest.mark.parametrize("shape", [((2, 2, 24, 32), (61, 83)), ((3, 17, 23), (17, 23)), ((1, 1, 32, 48), (480, 720)), ((2, 40, 30), (20, 15))])
+@pytest.mark.parametrize("shape", [((2, 2, 24, 32), (61, 83)), ((3, 17, 23), (17, 23)), ((1, 1, 32, 48), (480, 720)), ((2, 40, 30), (20, 15)),
+                                   ((3, 2, 240, 320), (480, 640)),      # x2: float4 tiles, the wide-load strip (320 px = 1.25 strips)
+                                   ((2, 320, 416), (768, 1000)),        # x2.4 in both axes, a last strip with idle lanes
+                                   ((2, 1, 90, 120), (100, 160)),       # x1.33 in x: tiled, but the four-float window does not hold
+                                   ((1, 2, 37, 52), (111, 208)),        # x4 in x, x3 in y
+                                   ((2, 7, 3), (20, 12)), ((1, 5, 4), (9, 8)),      # sources narrower than / exactly one window
+                                   ((2, 64, 80), (32, 40))])            # downsampling through the float4 path
 def test_upsample_fields_matches_torch_interpolate(dev, shape):
     """gclm_upsample_fields (GeoCalib._post_process, extractor.py:60-63) against F.interpolate bilinear."""
     from geocalib_amd.fields import upsample_fields
