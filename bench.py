@@ -14,7 +14,8 @@ before the timed region (counter-based generator keyed by (seed, global image in
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline:     achieved = algorithmic bytes of one sweep launch / mean sweep duration measured with
                 HIP events on the launch stream inside the timed region; peak = 8 TB/s HBM3E.
-  cpu_baseline: rank 0, N=1 only, on a bounded sample of the timed batch, on THIS box's host cores.  Where the reference
+  cpu_baseline: rank 0, at every N, after the last barrier, on a bounded sample of rank 0's timed batch, on THIS box's host
+                cores.  Where the reference
                 checkout exists on the box ($GEOCALIB_REFERENCE or /root/reference): the reference's OWN PyTorch CPU path
                 (geocalib/lm_optimizer.py:141, .eval(), no_grad) is timed -- kind "reference", measured_on "this box" --
                 with the CPU oracle (oracle/lm_oracle.c, a port) beside it as `port`.  Where it does not (the GPU box):
@@ -26,8 +27,12 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
                 (LMOptimizer.overlap_streams = 2, the library's default for large batches); `value` stays the one-stream run.
 The timed region (exactly --steps steps between barrier + synchronize) is run --repeats times; `value` and
 `ms_per_step` are the MEDIAN region (a 0.2-0.4 s window has a few % of run-to-run variance), all regions are listed.
+`value`, `ms_per_step` and `roofline` are measured on every rank's FIRST allocation of its input fields; at N = 1
+`placement.best_of_n` carries, beside them, the same measurement on the fastest-streaming of --placement-tries allocations
+(a serving loop may choose where its persistent field buffers live; the line of record does not).
 For N > 1 the line also carries `multi_gpu`: ranks_seen (from the communicator), per_rank_ms (every rank's own
-median step time) and collective_ms (device time inside the collectives per step, max over ranks).
+median step time) and collective_ms (device time inside the collectives per step, max over ranks); `roofline.per_rank_frac`
+lists every rank's own sweep fraction (its own HIP events) and `roofline.frac` is their MINIMUM.
 """
 import argparse
 import ctypes as C
@@ -72,8 +77,8 @@ def parse():
                          "roofline block is then measured in a separate one-stream pass (overlapping launches have no "
                          "separable durations)")
     ap.add_argument("--placement-tries", type=int, default=4,
-                    help="allocations of the input fields to choose the fastest-streaming one from, before any timing "
-                         "(geocalib_amd.fields.fastest_placement; 1 = take the first)")
+                    help="N = 1: allocations of the input fields tried for `placement.best_of_n`, AFTER the line of record (which "
+                         "is always measured on the first allocation); geocalib_amd.fields.fastest_placement; 1 = none")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="images for the CPU baseline (-1: auto, 0: skip)")
     ap.add_argument("--no-secondary", dest="secondary", action="store_false",
                     help="N=1 pinhole run: skip the `secondary` records (configs[3] simple_radial, configs[4] shared-16 shape)")
@@ -91,24 +96,38 @@ def parse():
 
 
 def cpu_baseline(args, n_images, host_data):
-    """The CPU baseline on a bounded sample: the FIRST n images of the very batch the GPU was timed on, already copied to
-    the host (numpy, float32).  Runs after the timed region, on rank 0 at N = 1 only.
+    """The CPU baseline on a bounded sample: the FIRST n images of the very batch rank 0's GPU was timed on, already copied
+    to the host (numpy, float32).  Runs on rank 0 after the timed regions and the last barrier, at every N (the other
+    ranks' processes are idle by then: the sample gets the box's granted cores to itself).
 
     The port (oracle/lm_oracle.c: a C restatement of the reference algorithm, OpenMP over images) is always timed.  Where
     the reference checkout exists on THIS box ($GEOCALIB_REFERENCE, default /root/reference) the reference's own PyTorch
     path is timed too, on the first `ref_images` of the same sample, and becomes the baseline of record
-    (kind "reference", measured_on "this box") with the port beside it."""
+    (kind "reference", measured_on "this box") with the port beside it.
+
+    --shared-group G: the sample is cut into groups of G frames, each solved as the reference solves a shared-intrinsics
+    batch (ONE group per call, lm_optimizer.py:350-383), one call after the other."""
     from oracle import lm_oracle, ref_import
     cores = lm_oracle.effective_cpus()        # what the cgroup grants, not what the box has
     lm_oracle.build()
+    group = getattr(args, "shared_group", 0)
+    if group:
+        n_images = max(group, n_images // group * group)
     data = {k: v[:n_images] for k, v in host_data.items()}
     conf = {"camera_model": args.camera_model, "num_steps": args.lm_steps, "early_stop": False}
     t0 = time.perf_counter()
-    lm_oracle.solve(data, conf, precision="f32", num_threads=cores)
+    if group:
+        for lo in range(0, n_images, group):
+            lm_oracle.solve({k: v[lo:lo + group] for k, v in data.items()}, {**conf, "shared_intrinsics": True}, precision="f32",
+                            num_threads=cores)
+    else:
+        lm_oracle.solve(data, conf, precision="f32", num_threads=cores)
     dt = time.perf_counter() - t0
-    port = {"value": round(n_images / dt, 3), "unit": "images/sec", "cores": min(cores, n_images), "kind": "port",
-            "sample": f"the first {n_images} images of the timed batch ({args.width}x{args.height}), {args.lm_steps} LM iters, "
-                      f"oracle/lm_oracle.c (float32, OpenMP over images), {dt:.1f} s"}
+    port = {"value": round(n_images / dt, 3), "unit": "images/sec" if not group else "frames/sec",
+            "cores": min(cores, group or n_images), "kind": "port",
+            "sample": f"the first {n_images} images of rank 0's timed batch ({args.width}x{args.height}), {args.lm_steps} LM iters, "
+                      + (f"as {n_images // group} shared-intrinsics groups of {group} frames, one call each, " if group else "")
+                      + f"oracle/lm_oracle.c (float32, OpenMP over images), {dt:.1f} s"}
     if ref_import.available():
         try:
             ref = reference_on_this_box(args, data, cores)
@@ -128,12 +147,13 @@ def reference_on_this_box(args, data, cores, ref_images=8):
     (B,N,2,P) Jacobians: several GB at B = 8 of 640x480), after one untimed single-image warm-up."""
     from oracle import ref_import
     ref = ref_import.load()
-    n = min(ref_images, next(iter(data.values())).shape[0])
+    group = getattr(args, "shared_group", 0)
+    n = min(group or ref_images, next(iter(data.values())).shape[0])
     prev = torch.get_num_threads()
     torch.set_num_threads(cores)
     try:
         opt = ref.lm_optimizer.LMOptimizer({"camera_model": args.camera_model, "num_steps": args.lm_steps,
-                                            "early_stop": False}).eval()
+                                            "early_stop": False, "shared_intrinsics": bool(group)}).eval()
         td = {k: torch.from_numpy(v[:n].copy()) for k, v in data.items()}
         with torch.no_grad():
             opt({k: v[:1] for k, v in td.items()})             # warm-up: thread pool, allocator
@@ -142,18 +162,19 @@ def reference_on_this_box(args, data, cores, ref_images=8):
             dt = time.perf_counter() - t0
     finally:
         torch.set_num_threads(prev)
-    return {"value": round(n / dt, 4), "unit": "images/sec", "cores": cores, "kind": "reference", "measured_on": "this box",
+    return {"value": round(n / dt, 4), "unit": "images/sec" if not group else "frames/sec", "cores": cores, "kind": "reference",
+            "measured_on": "this box",
             "code": f"{ref_import.REFERENCE_ROOT}/geocalib/lm_optimizer.py:141 LMOptimizer, .eval(), torch.no_grad(), CPU float32, "
                     f"torch {torch.__version__}, {cores} threads",
-            "sample": f"the first {n} images of the timed batch ({args.width}x{args.height}) as one batch, {args.lm_steps} LM "
-                      f"iters, {dt:.1f} s"}
+            "sample": f"the first {n} images of rank 0's timed batch ({args.width}x{args.height}) as one "
+                      f"{'shared-intrinsics group' if group else 'batch'}, {args.lm_steps} LM iters, {dt:.1f} s"}
 
 
 def reference_torch(args):
     """The reference's own CPU PyTorch timing for this camera model, as measured by scripts/cpu_reference_torch.py in
     the build container (the only place /root/reference exists); None when the file or the model is missing."""
     path = os.path.join(ROOT, "profiles", "cpu_reference_torch.json")
-    if not os.path.exists(path) or (args.height, args.width, args.lm_steps) != (480, 640, 20):
+    if not os.path.exists(path) or (args.height, args.width, args.lm_steps) != (480, 640, 20) or getattr(args, "shared_group", 0):
         return None
     with open(path) as fh:
         r = json.load(fh)
@@ -338,25 +359,13 @@ def main():
         comm = RcclComm.from_torch_group(local_dev)
     vworld = args.virtual_world or world
     placement = {"tries": max(args.placement_tries, 1), "solve_ms": None}
-    first_fields = []                 # the first allocation's fields (N = 1: timed beside the chosen one)
+    makers = []                       # how this rank's fields are made (N = 1: more allocations are tried AFTER the line of record)
 
     def place(make, optimizer):
-        """The input fields of this rank: the fastest-streaming of --placement-tries allocations (same content; chosen by
-        a LOCAL solve before any timed region, no collective: every rank chooses for its own GPU)."""
-        truth = []
-
-        def allocate():
-            d, c, g = make()
-            truth.append((c, g))
-            return d
-        free_bytes = torch.cuda.mem_get_info(dev)[0]
-        placement["tries"] = max(1, min(placement["tries"], int(0.8 * free_bytes // (B * H * W * PLANES * 4))))   # all candidates are alive at once
-        fields, ms, first = fastest_placement(allocate, optimizer, placement["tries"], keep_first=True)
-        placement["solve_ms"] = [round(t, 3) for t in ms] or None
-        placement["chosen"] = ms.index(min(ms)) if ms else 0
-        if world == 1 and placement["chosen"] != 0:
-            first_fields.append(first)
-        return fields, truth[0][0], truth[0][1]          # the ground truth is the same for every candidate
+        """The input fields of this rank: the FIRST allocation -- what a caller who allocates once gets.  `value`,
+        `ms_per_step` and `roofline` are measured on it, at every N (no choice among allocations enters the line of record)."""
+        makers.append(make)
+        return make()
 
     if gs == 0:
         # independent intrinsics: rank r owns the contiguous images [r*B, (r+1)*B)
@@ -437,19 +446,6 @@ def main():
         regions.append(time.perf_counter() - t0)
     own = sorted(regions)[len(regions) // 2]              # this rank's median region
     coll_ms = ctimer.total_ms() / (len(regions) * args.steps)
-    ranks_seen, per_rank_ms, coll_ms_max = world, [own / args.steps * 1e3], coll_ms
-    if distributed:
-        tdev = dev if args.backend == "nccl" else "cpu"
-        t = torch.tensor(regions, device=tdev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)           # every region: MAX over ranks, then the median region
-        regions = t.tolist()
-        ranks_seen = dist.get_world_size()
-        mine = torch.tensor([own / args.steps * 1e3, coll_ms], device=tdev, dtype=torch.float64)
-        allr = [torch.zeros_like(mine) for _ in range(ranks_seen)]
-        dist.all_gather(allr, mine)
-        per_rank_ms = [round(x[0].item(), 4) for x in allr]
-        coll_ms_max = max(x[1].item() for x in allr)
-    elapsed = sorted(regions)[len(regions) // 2]
     sweep_ms, sweep_n = 0.0, 0
     if presweep is not None:
         sweep_ms, sweep_n = presweep
@@ -457,6 +453,27 @@ def main():
         n, ms = C.c_int(0), C.c_float(0)
         _lib.check(lib.gclm_last_pass_timing(handle.ptr, C.byref(n), C.byref(ms)), handle.ptr, "timing")
         sweep_ms, sweep_n = ms.value, n.value
+    algo_bytes_per_launch = B * H * W * PLANES * 4
+
+    def algo_frac(avg_launch_ms):
+        """algorithmic bytes of one sweep launch / its duration, as a fraction of the HBM peak"""
+        return algo_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+
+    own_sweep_ms = sweep_ms / sweep_n if sweep_n else 0.0
+    ranks_seen, per_rank_ms, coll_ms_max, per_rank_sweep_ms = world, [own / args.steps * 1e3], coll_ms, [own_sweep_ms]
+    if distributed:
+        tdev = dev if args.backend == "nccl" else "cpu"
+        t = torch.tensor(regions, device=tdev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)           # every region: MAX over ranks, then the median region
+        regions = t.tolist()
+        ranks_seen = dist.get_world_size()
+        mine = torch.tensor([own / args.steps * 1e3, coll_ms, own_sweep_ms], device=tdev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(ranks_seen)]
+        dist.all_gather(allr, mine)
+        per_rank_ms = [round(x[0].item(), 4) for x in allr]
+        coll_ms_max = max(x[1].item() for x in allr)
+        per_rank_sweep_ms = [x[2].item() for x in allr]     # every rank's own mean sweep launch (its own HIP events)
+    elapsed = sorted(regions)[len(regions) // 2]
 
     # sanity: the solve must have recovered the synthetic ground truth (a fast wrong answer is no answer)
     cam = out["camera"]._data
@@ -482,12 +499,30 @@ def main():
     solo = world == 1 and not distributed and gs == 0 and not overlapped
     if solo:
         lib.gclm_set_timing(handle.ptr, 0)
-        if first_fields:
-            # what a caller who allocates ONCE gets on this box: the same steps on the first allocation's fields
-            opt(first_fields[0])
-            sec = timed_regions(lambda: opt(first_fields[0]), 1)
-            placement["first_allocation"] = {"value": round(B * args.steps / sec, 1), "ms_per_step": round(sec / args.steps * 1e3, 4)}
-            first_fields.clear()
+        if placement["tries"] > 1:
+            # beside the line of record: what a serving loop that CHOOSES among allocations of its persistent field buffers
+            # gets on this box (geocalib_amd.fields.fastest_placement) -- the first allocation is candidate 0
+            free_bytes = torch.cuda.mem_get_info(dev)[0]
+            tries = max(1, min(placement["tries"], 1 + int(0.8 * free_bytes // (B * H * W * PLANES * 4))))   # all alive at once
+            pending = [data]
+            chosen, ms, _ = fastest_placement(lambda: pending.pop() if pending else makers[0]()[0], opt, tries, keep_first=True)
+            placement.update(tries=tries, solve_ms=[round(t, 3) for t in ms] or None, chosen=ms.index(min(ms)) if ms else 0)
+            best = {"chosen": placement["chosen"], "value": round(B * args.steps / elapsed, 1),
+                    "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                    "frac": round(algo_frac(sweep_ms / sweep_n), 4) if sweep_n else None}
+            if placement["chosen"] != 0:
+                if not args.no_timing:
+                    lib.gclm_set_timing(handle.ptr, 1)
+                opt(chosen)
+                sec = timed_regions(lambda: opt(chosen), max(args.repeats, 1))
+                best.update(value=round(B * args.steps / sec, 1), ms_per_step=round(sec / args.steps * 1e3, 4))
+                if not args.no_timing:
+                    n, ms_ = C.c_int(0), C.c_float(0)
+                    _lib.check(lib.gclm_last_pass_timing(handle.ptr, C.byref(n), C.byref(ms_)), handle.ptr, "timing")
+                    lib.gclm_set_timing(handle.ptr, 0)
+                    best["frac"] = round(algo_frac(ms_.value / max(n.value, 1)), 4)
+            placement["best_of_n"] = best
+            del chosen
         if not args.no_overlap and B >= 512:
             # the library's default for a batch this large: two halves on two side streams, one part's update launches
             # under the other's sweep (LMOptimizer.overlap_streams); results must be the one-stream solve's, bit for bit
@@ -503,9 +538,11 @@ def main():
                                  "bit_identical": bool(same),
                                  "whole_job_frac": round(v2 * (args.lm_steps + 1) * H * W * PLANES * 4 / 1e9 / HBM_PEAK_GBS, 4)}
     host_sample = None
-    if rank == 0 and world == 1 and args.cpu_sample != 0 and gs == 0:
+    if rank == 0 and args.cpu_sample != 0:
         from oracle.lm_oracle import effective_cpus
         n_cpu = min(B, args.cpu_sample if args.cpu_sample > 0 else max(8, 16 * effective_cpus()))   # ~7-10 s of CPU work
+        if gs:
+            n_cpu = min(B, max(gs, n_cpu // gs * gs))      # whole groups of the sample (any gs frames: the work is the same)
         host_sample = {k: v[:n_cpu].cpu().numpy() for k, v in data.items()}
     if solo and args.secondary and args.camera_model == "pinhole":
         del data, out
@@ -515,9 +552,10 @@ def main():
             "shared16_pinhole": quick_case(lib, LMOptimizer, synth_fields, dev, "pinhole", B, H, W, args.lm_steps, args.seed, 16),
         }
 
+    if "best_of_n" not in placement:
+        placement["tries"] = 1            # (N > 1, shared intrinsics, --streams: the first allocation and nothing else)
     if rank == 0:
         value = n_total * args.steps / elapsed
-        algo_bytes_per_launch = B * H * W * PLANES * 4
         result = {
             "metric": "images/sec LM calibration (640x480, 20 iters)", "value": round(value, 1),
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -541,10 +579,10 @@ def main():
                                        f"group-sharded x{world}, one all-gather of results" if args.shared_by_group else
                                        f"frames of every group split x{world}, one all-reduce per LM step")},
             "check": {"median_focal_rel_err_vs_gt": f_err, "median_gravity_abs_err_vs_gt": g_err},
-            "placement": {**placement, "what": "rank 0's input fields were allocated `tries` times before any timing and the "
-                          "allocation whose solve ran fastest was kept (geocalib_amd.fields.fastest_placement, DESIGN.md 3.1): "
-                          "`value` is measured on the CHOSEN allocation, `first_allocation` (N = 1; absent when the first one "
-                          "was chosen) is the same measurement on the first"},
+            "placement": {**placement, "what": "`value`, `ms_per_step` and `roofline` are measured on every rank's FIRST allocation of "
+                          "its input fields (no choice among allocations).  N = 1 only, after the line of record: `tries` - 1 more "
+                          "allocations are made and `best_of_n` is the same measurement on the allocation whose solve ran fastest "
+                          "(geocalib_amd.fields.fastest_placement, DESIGN.md 9.1; candidate 0 = the first allocation)"},
         }
         result.update(extras)
         if distributed:
@@ -562,8 +600,10 @@ def main():
                 "launched_by": "bench.py itself (torch.distributed.run child)" if os.environ.get("GCLM_BENCH_SELF_LAUNCHED") == "1"
                                else "an external launcher",
                 "rccl": rccl_versions(lib)}
-        if sweep_n:
-            avg_ms = sweep_ms / sweep_n
+        if sweep_n and all(t > 0 for t in per_rank_sweep_ms):
+            # every rank's own mean sweep launch; the line's `frac` / `achieved` are the SLOWEST rank's (N = 1: the only one)
+            per_rank_frac = [round(algo_frac(t), 4) for t in per_rank_sweep_ms]
+            avg_ms = max(per_rank_sweep_ms)
             achieved = algo_bytes_per_launch / (avg_ms * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -578,7 +618,8 @@ def main():
                 "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command, committed; not "
                                   "re-measured in this run)" if traffic is not None else None,
                 "algorithmic_bytes_per_launch": algo_bytes_per_launch, "avg_launch_ms": round(avg_ms, 4),
-                "launches_timed": sweep_n,
+                "launches_timed": sweep_n, "per_rank_frac": per_rank_frac,
+                "per_rank_avg_launch_ms": [round(t, 4) for t in per_rank_sweep_ms],
                 "measured_in": (f"a separate pass of {args.steps} steps on ONE stream before the timed regions: the timed steps "
                                 f"solve {args.streams} parts of the batch concurrently, whose launch durations overlap and are "
                                 "not separable" if overlapped else "the timed regions"),

@@ -45,7 +45,10 @@ struct gclm_handle {
         const float *up = nullptr, *lat = nullptr, *upc = nullptr, *latc = nullptr;
         float *cam_io = nullptr, *grav_io = nullptr;
         Geometry geo{};
+        bool slat_ready = false;    // the scratch plane holds sin(latitude) of this session's fields
     } sh;
+    float* slat = nullptr;          // carved view: scratch plane (B, H, W) of sin(latitude_field), or null (see slat_wanted)
+    int slat_plane = -1;            // gclm_set_slat_plane: -1 = built-in choice, 0 = never, 1 = wherever the sweep has it
     int sweep_iters = 0;            // gclm_set_sweep_iters: 0 = built-in choice
     int fused_mode = -1;            // gclm_set_fused_steps: -1 = built-in choice, 0 = never, 1 = whenever it is valid
     gclm_comm* stop_comm = nullptr; // gclm_set_stop_comm: the batch-global early stop spans the ranks of this communicator
@@ -125,8 +128,10 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 bool is_aligned16(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// Carve the workspace for B images / nchunks partial records per image / G groups.
-int ensure_workspace(gclm_handle* h, int B, int nchunks, int G) {
+// Carve the workspace for B images / nchunks partial records per image / G groups, plus `slat_floats` floats of
+// scratch plane (0: none).  Growing it frees and re-allocates (hipFree synchronises the device ONCE, on the first call
+// of a larger shape than any before; every later call finds the workspace in place -- include/gclm.h says so).
+int ensure_workspace(gclm_handle* h, int B, int nchunks, int G, size_t slat_floats = 0) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_state0 = take(sizeof(State) * B), o_state1 = take(sizeof(State) * B);
@@ -136,6 +141,7 @@ int ensure_workspace(gclm_handle* h, int B, int nchunks, int G) {
     const size_t o_fsys = take(sizeof(float) * kNAccMax * (size_t)B);
     const size_t o_gp = take(sizeof(float) * GCLM_SHARED_PARTIAL_STRIDE * (size_t)(G > 0 ? G : 1));
     const size_t o_ctrl = take(sizeof(Ctrl));
+    const size_t o_slat = take(sizeof(float) * slat_floats);
     if (off > h->ws_bytes) {
         if (h->ws) GCLM_HIP(h, hipFree(h->ws));
         h->ws = nullptr;
@@ -156,7 +162,26 @@ int ensure_workspace(gclm_handle* h, int B, int nchunks, int G) {
     c.frame_sys = reinterpret_cast<float*>(base + o_fsys);
     c.ctrl = reinterpret_cast<Ctrl*>(base + o_ctrl);
     h->group_partials = reinterpret_cast<float*>(base + o_gp);
+    h->slat = slat_floats ? reinterpret_cast<float*>(base + o_slat) : nullptr;
     return 0;
+}
+
+// Does this solve keep sin(latitude_field) in a scratch plane (gclm_pass.hip: row_math, SLAT)?  Built-in choice: the
+// VALU-bound distortion models, on the five-plane float4 sweep, whenever at least one loop sweep precedes the final one.
+// Pinhole never (memory-bound: the plane's extra write costs what the saved arithmetic gains); not the one-launch-per-step
+// path (latency-bound, a handful of workgroups).
+bool slat_wanted(const gclm_handle* h, const float* up, const float* upc, const float* latc, const Geometry& g, bool fused) {
+    if (h->slat_plane == 0 || fused || g.vec != 4 || !up || !upc || !latc || h->cfg.num_steps < 1) return false;
+    if (h->slat_plane < 0 && h->cfg.camera_model == GCLM_PINHOLE) return false;
+    return sweep_has_slat_plane(h->cfg.camera_model);
+}
+
+// The sweep arguments of the next sweep of a solve that keeps the scratch plane: the first one fills it, the others read it
+void apply_slat(const gclm_handle* h, SweepArgs& a, bool& ready) {
+    if (!h->slat) return;
+    a.slat = h->slat;
+    if (ready) { a.slat_mode = 2; a.lat = h->slat; }
+    else { a.slat_mode = 1; ready = true; }
 }
 
 SweepArgs sweep_args(const gclm_handle* h, const float* up, const float* lat, const float* upc, const float* latc,
@@ -361,6 +386,14 @@ int gclm_set_sweep_iters(gclm_handle* h, int iters) {
     return 0;
 }
 
+int gclm_set_slat_plane(gclm_handle* h, int mode) {
+    if (!h) return -1;
+    if (mode < -1 || mode > 1) return fail(h, -3, "gclm_set_slat_plane: mode %d not in {-1, 0, 1}", mode);
+    h->slat_plane = mode;
+    h->sh.active = false;
+    return 0;
+}
+
 int gclm_set_stop_comm(gclm_handle* h, gclm_comm* c) {
     if (!h) return -1;
     h->stop_comm = c;
@@ -471,11 +504,13 @@ static int run_solve(gclm_handle* h, const float* d_up, const float* d_lat, cons
     // (only where the sweep HAS a log-focal instantiation: a -DGCLM_LOGF=0 build of gclm_pass.hip takes the general column)
     c.iso_final = (ia.cam == nullptr && ia.scales == nullptr && GCLM_ISO_FINAL && sweep_has_log_focal()) ? 1 : 0;
     if (int rc = setup_groups(h, B)) return rc;
-    if (int rc = ensure_workspace(h, B, geo.nchunks, c.n_groups)) return rc;
-    h->sh.active = false;
-
     const bool es = h->cfg.early_stop != 0;
     const bool fused_path = use_fused(h, B, geo);
+    const bool keep_slat = slat_wanted(h, d_up, d_up_conf, d_lat_conf, geo, fused_path);
+    if (int rc = ensure_workspace(h, B, geo.nchunks, c.n_groups, keep_slat ? (size_t)B * H * W : 0)) return rc;
+    h->sh.active = false;
+    bool slat_ready = false;
+
     if (!fused_path) GCLM_HIP(h, launch_init(c, ia, s));      // (the one-launch-per-step path builds theta_0 in its first launch)
     if (fused_path) {
         // fused(step) x num_steps | fused(final) | finalize : num_steps + 2 launches, partial records double-buffered
@@ -535,7 +570,8 @@ static int run_solve(gclm_handle* h, const float* d_up, const float* d_lat, cons
         return 0;
     }
     for (int step = 0; step < h->cfg.num_steps; ++step) {
-        const SweepArgs a = sweep_args(h, d_up, d_lat, d_up_conf, d_lat_conf, c.pb[step & 1], geo, true, es ? step : 0);
+        SweepArgs a = sweep_args(h, d_up, d_lat, d_up_conf, d_lat_conf, c.pb[step & 1], geo, true, es ? step : 0);
+        apply_slat(h, a, slat_ready);
         if (int rc = timed_sweep(h, a, s)) return rc;
         if (!h->cfg.shared_intrinsics) {
             GCLM_HIP(h, launch_update(c, step, s));
@@ -549,7 +585,8 @@ static int run_solve(gclm_handle* h, const float* d_up, const float* d_lat, cons
                 return fail(h, -20, "early-stop all-reduce failed: %s", gclm_comm_last_error(h->stop_comm));
     }
     GCLM_HIP(h, launch_prep_final(c, s));
-    const SweepArgs a = sweep_args(h, d_up, d_lat, d_up_conf, d_lat_conf, c.pb_final, geo, false, 0);
+    SweepArgs a = sweep_args(h, d_up, d_lat, d_up_conf, d_lat_conf, c.pb_final, geo, false, 0);
+    apply_slat(h, a, slat_ready);
     if (int rc = timed_sweep(h, a, s)) return rc;
     GCLM_HIP(h, launch_finalize(c, d_cam_out, d_grav_out, d_info_out, s));
     return 0;
@@ -631,7 +668,9 @@ int gclm_shared_begin(gclm_handle* h, const float* d_up, const float* d_lat, con
     c.cfg = h->cfg;
     c.B = B_local; c.H = H; c.W = W; c.nchunks = h->sh.geo.nchunks;
     c.n_groups = num_groups; c.group_size = 1; c.group_of_frame = d_group_of_frame; c.iso_final = 0;
-    if (int rc = ensure_workspace(h, Bp, h->sh.geo.nchunks, num_groups)) return rc;
+    const bool keep_slat = B_local > 0 && slat_wanted(h, d_up, d_up_conf, d_lat_conf, h->sh.geo, false);
+    if (int rc = ensure_workspace(h, Bp, h->sh.geo.nchunks, num_groups, keep_slat ? (size_t)B_local * H * W : 0)) return rc;
+    h->sh.slat_ready = false;
     h->sh.up = d_up; h->sh.lat = d_lat; h->sh.upc = d_up_conf; h->sh.latc = d_lat_conf;
     h->sh.cam_io = d_cam_io; h->sh.grav_io = d_grav_io;
     h->sh.active = true;
@@ -651,7 +690,8 @@ int gclm_shared_reduce(gclm_handle* h, int step, float* d_partials, void* stream
     GCLM_HIP(h, guard.status);
     SolveCtx& c = h->ctx;
     if (c.B > 0) {
-        const SweepArgs a = sweep_args(h, h->sh.up, h->sh.lat, h->sh.upc, h->sh.latc, c.pb[step & 1], h->sh.geo, true, 0);
+        SweepArgs a = sweep_args(h, h->sh.up, h->sh.lat, h->sh.upc, h->sh.latc, c.pb[step & 1], h->sh.geo, true, 0);
+        apply_slat(h, a, h->sh.slat_ready);
         if (int rc = timed_sweep(h, a, s)) return rc;
     }
     GCLM_HIP(h, launch_shared_reduce(c, step, d_partials, s));
@@ -680,7 +720,8 @@ int gclm_shared_finish(gclm_handle* h, float* d_info_out, void* stream) {
     h->sh.active = false;
     if (c.B == 0) return 0;
     GCLM_HIP(h, launch_prep_final(c, s));
-    const SweepArgs a = sweep_args(h, h->sh.up, h->sh.lat, h->sh.upc, h->sh.latc, c.pb_final, h->sh.geo, false, 0);
+    SweepArgs a = sweep_args(h, h->sh.up, h->sh.lat, h->sh.upc, h->sh.latc, c.pb_final, h->sh.geo, false, 0);
+    apply_slat(h, a, h->sh.slat_ready);
     if (int rc = timed_sweep(h, a, s)) return rc;
     GCLM_HIP(h, launch_finalize(c, h->sh.cam_io, h->sh.grav_io, d_info_out, s));
     return 0;

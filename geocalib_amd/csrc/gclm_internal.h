@@ -84,6 +84,9 @@ struct SweepArgs {
     int log_focal;          // the parameter block was built for the log-focal parametrisation (wfx = wfy = 1)
     int stop_step;          // >= 2: LM step of this loop sweep, skipped once the early stop has fired (else 0)
     float up_scale, lat_scale;   // Huber scales a (lm_optimizer.py:158-159)
+    float* slat;            // library-owned scratch plane (B,H,W) of sin(latitude_field), or nullptr (gclm_pass.hip: row_math)
+    int slat_mode;          // 0: `lat` holds radians, nothing is stored; 1: ... and this sweep fills `slat`;
+                            // 2: `lat` IS the filled scratch plane (sin(latitude) is loaded, not computed)
 };
 
 struct SolveCtx;
@@ -152,6 +155,7 @@ constexpr unsigned kPacedEpochShift = 20, kPacedEpochMask = 0xfffu;
 constexpr int kPacedPatienceUs = 2000;    // host wait for one report before the rest of the solve is issued unpaced ...
 constexpr int kPacedCooldown = 64;        // ... and solves of that handle that then do not pace at all
 bool sweep_has_log_focal();               // gclm_pass.hip: false in a -DGCLM_LOGF=0 measurement build
+bool sweep_has_slat_plane(int camera_model);   // gclm_pass.hip: the model's five-plane float4 sweep has the SLAT instantiations
 constexpr int kMaxMergeParts = 8;
 struct MergeStopArgs {          // gclm_merge_stop_at: parts of one batch solved by separate handles
     const Ctrl* ctrl[kMaxMergeParts];

@@ -93,6 +93,11 @@
 #ifndef GCLM_EPS_FMA
 #define GCLM_EPS_FMA 1              // A/B switch: 0 = max(|q|^2, 1e-24) as a separate v_max_f32 (rounds 1-3)
 #endif
+#ifndef GCLM_SLAT_PINHOLE
+#define GCLM_SLAT_PINHOLE 1         // the pinhole sweep has the sin(latitude) scratch-plane instantiations too; the library's
+                                    // built-in choice does not use them (memory-bound: the plane's one extra write costs
+                                    // what the saved VALU work gains), gclm_set_slat_plane(h, 1) does (measurement)
+#endif
 #ifndef GCLM_DIV_GUARD_ALWAYS
 #define GCLM_DIV_GUARD_ALWAYS 0     // A/B switch: 1 = simple_divisional always runs the guarded body (round-2 behaviour)
 #endif
@@ -818,6 +823,12 @@ struct Lane<4> {
 #endif
         return make_float4(t.x, t.y, t.z, t.w);
     }
+    // the lane's four sin(latitude) values into the library's scratch plane (read back once per later sweep: streamed)
+    static __device__ __forceinline__ void st(float* base, uint32_t byte_off, const F (&v)[2]) {
+        typedef float v4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(v4{v[0].x, v[0].y, v[1].x, v[1].y},
+                                    reinterpret_cast<v4*>(reinterpret_cast<char*>(base) + byte_off));
+    }
     static __device__ __forceinline__ F get(const V& v, int k) { return k == 0 ? f2{v.x, v.y} : f2{v.z, v.w}; }
     static __device__ __forceinline__ V ones() { return make_float4(1.f, 1.f, 1.f, 1.f); }
     static __device__ __forceinline__ bool any_zero(F a) { return a.x == 0.f || a.y == 0.f; }
@@ -835,6 +846,9 @@ struct Lane<1> {
     static constexpr int kPairs = 1;
     static __device__ __forceinline__ V ld(const float* base, uint32_t byte_off) {
         return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+    }
+    static __device__ __forceinline__ void st(float* base, uint32_t byte_off, const F (&v)[1]) {
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v[0];
     }
     static __device__ __forceinline__ F get(const V& v, int) { return v; }
     static __device__ __forceinline__ V ones() { return 1.f; }
@@ -892,18 +906,31 @@ __device__ __forceinline__ RowData<VEC> load_row(const float* upx, const float* 
     return r;
 }
 
-// The math of one loop iteration: image row y of the lane's column(s), from the loaded values into the accumulators
-template <int MODEL, bool HAS_UP, bool LOGF, int VEC>
+// The math of one loop iteration: image row y of the lane's column(s), from the loaded values into the accumulators.
+//
+// SLAT -- sin(latitude_field) (lm_optimizer.py:262,270) does not depend on the parameters, yet every sweep of a solve would
+// re-evaluate it per pixel (7 packed ops per pixel pair + the range test: ~18 of simple_radial's 265 VALU instructions per
+// 4 pixels).  The VALU-bound distortion models therefore keep it in a LIBRARY-owned scratch plane (B x N floats in the
+// handle's workspace; the boundary is unchanged: the caller still hands radians):
+//   SLAT = 0  compute, keep in registers (pinhole; the one-launch-per-step kernel; the stand-alone stages)
+//   SLAT = 1  compute as above AND store the plane (the first sweep of a solve; `slat_out` + `off`)
+//   SLAT = 2  the `lat` plane of this launch IS that scratch plane: the loaded value is sin(latitude) (every later sweep)
+// Same polynomial, same bits: a float stored and loaded is the float that was computed.
+template <int MODEL, bool HAS_UP, bool LOGF, int VEC, int SLAT = 0>
 __device__ __forceinline__ void row_math(const PBlock& P, const HuberK& hk, const typename Lane<VEC>::F (&col_u)[Lane<VEC>::kPairs],
                                          const typename Lane<VEC>::F (&col_px)[Lane<VEC>::kPairs], const int y,
                                          const RowData<VEC>& r, typename Lane<VEC>::F (&acc)[Layout<MODEL>::NACC],
-                                         [[maybe_unused]] const bool col_zero, [[maybe_unused]] const bool div_k_tiny) {
+                                         [[maybe_unused]] const bool col_zero, [[maybe_unused]] const bool div_k_tiny,
+                                         [[maybe_unused]] float* slat_out = nullptr, [[maybe_unused]] const uint32_t off = 0) {
     using L = Lane<VEC>;
     using F = typename L::F;
     // latitudes beyond +-pi/2 (never from the CNN head; a caller's own field may hold them): fold them into the
     // polynomial's range.  Wave-uniform branch on a ballot: in-range data pays one max3 / max / cmp per 4 pixels.
     F slat[L::kPairs];
-    {
+    if constexpr (SLAT == 2) {
+#pragma unroll
+        for (int k = 0; k < L::kPairs; ++k) slat[k] = L::get(r.vlat, k);
+    } else {
         F lt[L::kPairs], t[L::kPairs];
 #pragma unroll
         for (int k = 0; k < L::kPairs; ++k) { lt[k] = L::get(r.vlat, k); t[k] = lt[k] * lt[k]; }
@@ -913,6 +940,7 @@ __device__ __forceinline__ void row_math(const PBlock& P, const HuberK& hk, cons
         }
 #pragma unroll
         for (int k = 0; k < L::kPairs; ++k) slat[k] = sin_halfpi(lt[k], t[k]);
+        if constexpr (SLAT == 1) L::st(slat_out, off, slat);
     }
     const float v = ((float)y - P.cy) * P.ify;
 #if GCLM_NOMATH     // measurement only: the memory-system ceiling of this exact access pattern
@@ -960,7 +988,7 @@ __device__ __forceinline__ void row_math(const PBlock& P, const HuberK& hk, cons
 //
 // PRE > 0 (one-launch-per-step kernel only): the values of the lane's first PRE iterations were requested by the caller
 // before its prologue (`pre`, with the lane's job `pj`), so their memory round trip runs under the prologue's.
-template <int MODEL, bool HAS_UP, bool HAS_UPC, bool HAS_LATC, bool LOGF, int VEC, int PRE = 0>
+template <int MODEL, bool HAS_UP, bool HAS_UPC, bool HAS_LATC, bool LOGF, int VEC, int PRE = 0, int SLAT = 0>
 __device__ __forceinline__ void sweep_body(const SweepArgs& a, const PBlock& P, const int b, const int chunk,
                                            [[maybe_unused]] const LaneJob<VEC>* pj = nullptr,
                                            [[maybe_unused]] const RowData<VEC>* pre = nullptr) {
@@ -975,9 +1003,10 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const PBlock& P, 
     const size_t N = (size_t)a.H * a.W;
     const float* upx = HAS_UP ? a.up + (size_t)b * 2 * N : nullptr;
     const float* upy = HAS_UP ? upx + N : nullptr;
-    const float* lat = a.lat + (size_t)b * N;
+    const float* lat = a.lat + (size_t)b * N;             // (SLAT == 2: the scratch plane of sin(latitude), see row_math)
     const float* upc = HAS_UPC ? a.upc + (size_t)b * N : nullptr;
     const float* latc = HAS_LATC ? a.latc + (size_t)b * N : nullptr;
+    [[maybe_unused]] float* slat_out = SLAT == 1 ? a.slat + (size_t)b * N : nullptr;
 
     using L = Lane<VEC>;
     using F = typename L::F;
@@ -1023,7 +1052,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const PBlock& P, 
             // keep every load of the iteration ahead of the math: left alone, the scheduler sinks loads next to
             // their first use to save registers in some instantiations (load -> wait -> use, five times over)
             __builtin_amdgcn_sched_barrier(0);
-            row_math<MODEL, HAS_UP, LOGF, VEC>(P, hk, col_u, col_px, y, r, acc, col_zero, div_k_tiny);
+            row_math<MODEL, HAS_UP, LOGF, VEC, SLAT>(P, hk, col_u, col_px, y, r, acc, col_zero, div_k_tiny, slat_out, off);
         }
     }
 
@@ -1062,9 +1091,10 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const PBlock& P, 
 
 // launch bounds: radial / simple_divisional are held to 168 VGPRs (3 waves per SIMD); simple_radial reaches 112 (4 waves)
 // on its own; the log-focal pinhole sweep is held to 80 (6 waves: the latitude range test of round 3 took it to 82
-// otherwise; the general-focal instantiation would spill at 80 and keeps its own 96)
-template <int MODEL, bool HAS_UP, bool HAS_UPC, bool HAS_LATC, bool LOGF, int VEC>
-__global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL == GCLM_RADIAL) ? GCLM_RADIAL_WAVES : (VEC == 4 && MODEL > GCLM_RADIAL) ? GCLM_DIV_WAVES : (VEC == 4 && MODEL == GCLM_SIMPLE_RADIAL) ? 4 : (VEC == 4 && MODEL == GCLM_PINHOLE && LOGF) ? GCLM_PINHOLE_WAVES : GCLM_MIN_WAVES) void sweep_kernel(
+// otherwise; the general-focal instantiation would spill at 80 and keeps its own 96, and so do the scratch-plane
+// instantiations SLAT != 0, which the library's built-in choice never launches for pinhole)
+template <int MODEL, bool HAS_UP, bool HAS_UPC, bool HAS_LATC, bool LOGF, int VEC, int SLAT = 0>
+__global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL == GCLM_RADIAL) ? GCLM_RADIAL_WAVES : (VEC == 4 && MODEL > GCLM_RADIAL) ? GCLM_DIV_WAVES : (VEC == 4 && MODEL == GCLM_SIMPLE_RADIAL) ? 4 : (VEC == 4 && MODEL == GCLM_PINHOLE && LOGF) ? (SLAT == 0 ? GCLM_PINHOLE_WAVES : 5) : GCLM_MIN_WAVES) void sweep_kernel(
     const SweepArgs a) {
     if (stop_fired_before(a.ctrl, a.stop_step)) return;   // batch-global early stop, no host sync
 #if GCLM_XCD_REMAP      // A/B switch: each XCD (block id % 8) walks a contiguous eighth of the batch
@@ -1081,7 +1111,7 @@ __global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL == GCLM_RADIAL) ? GCLM_R
     const int b = blockIdx.y, chunk = blockIdx.x;
 #endif
     const PBlock P = a.pb[b];                            // workgroup-uniform -> scalar loads
-    sweep_body<MODEL, HAS_UP, HAS_UPC, HAS_LATC, LOGF, VEC>(a, P, b, chunk);
+    sweep_body<MODEL, HAS_UP, HAS_UPC, HAS_LATC, LOGF, VEC, 0, SLAT>(a, P, b, chunk);
 }
 
 // ONE launch per LM step for small batches (the interactive B = 1 case of the reference's demo, interactive_demo.py:403):
@@ -1387,6 +1417,22 @@ hipError_t dispatch(const SweepArgs& a, hipStream_t s) {
         if (logf) hipLaunchKernelGGL((sweep_kernel<MODEL, U, UC, LC, VEC == 4, VEC>), grid, block, 0, s, a); \
         else hipLaunchKernelGGL((sweep_kernel<MODEL, U, UC, LC, false, VEC>), grid, block, 0, s, a);    \
     } while (0)
+    // the sin(latitude) scratch plane (row_math: SLAT) exists for the five-plane float4 sweeps of the distortion models
+    if constexpr (VEC == 4 && (MODEL != GCLM_PINHOLE || GCLM_SLAT_PINHOLE)) {
+        if (a.slat_mode != 0) {
+            if (!(up && upc && latc) || a.slat == nullptr || a.slat_mode < 0 || a.slat_mode > 2) return hipErrorInvalidValue;
+#define GCLM_LAUNCH_SLAT(LF)                                                                                         \
+    do {                                                                                                             \
+        if (a.slat_mode == 1) hipLaunchKernelGGL((sweep_kernel<MODEL, true, true, true, LF, 4, 1>), grid, block, 0, s, a); \
+        else hipLaunchKernelGGL((sweep_kernel<MODEL, true, true, true, LF, 4, 2>), grid, block, 0, s, a);            \
+    } while (0)
+            if (logf) GCLM_LAUNCH_SLAT(true); else GCLM_LAUNCH_SLAT(false);
+#undef GCLM_LAUNCH_SLAT
+            return hipGetLastError();
+        }
+    } else if (a.slat_mode != 0) {
+        return hipErrorInvalidValue;
+    }
     if (up) {
         if (upc) { if (latc) GCLM_LAUNCH(true, true, true); else GCLM_LAUNCH(true, true, false); }
         else     { if (latc) GCLM_LAUNCH(true, false, true); else GCLM_LAUNCH(true, false, false); }
@@ -1436,6 +1482,10 @@ hipError_t launch_sweep(int camera_model, const SweepArgs& a, hipStream_t s) {
 }
 
 bool sweep_has_log_focal() { return GCLM_LOGF != 0; }
+
+bool sweep_has_slat_plane(int camera_model) {
+    return camera_model > GCLM_PINHOLE ? camera_model <= GCLM_SIMPLE_DIVISIONAL : (camera_model == GCLM_PINHOLE && GCLM_SLAT_PINHOLE != 0);
+}
 
 hipError_t launch_fused_step(int camera_model, const SweepArgs& a, const FusedArgs& f, hipStream_t s) {
     if (a.B <= 0) return hipSuccess;

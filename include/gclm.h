@@ -35,9 +35,9 @@ extern "C" {
  * struct_size / abi_version / device moved into gclm_config, gclm_create lost its third argument, new entry points
  * gclm_set_sweep_iters, gclm_set_fused_steps, gclm_set_paced_launches, gclm_set_stop_comm, gclm_comm_all_reduce_sum_i32,
  * gclm_abi_config_size; 400 = round 4: gclm_comm_versions, gclm_merge_stop_at and gclm_upsample_fields_multi added, the NULL-handle error strings became thread-local, an
- * empty batch (B = 0, NULL fields) is accepted by gclm_solve / gclm_calibrate).  gclm_create refuses a gclm_config whose first two fields do not
+ * empty batch (B = 0, NULL fields) is accepted by gclm_solve / gclm_calibrate; 500 = round 5: gclm_set_slat_plane added).  gclm_create refuses a gclm_config whose first two fields do not
  * carry the library's own sizeof(gclm_config) and GCLM_VERSION, with a message naming both sides. */
-#define GCLM_VERSION 400
+#define GCLM_VERSION 500
 
 /* camera_models of geocalib/camera.py:945-950 */
 enum gclm_camera_model {
@@ -327,6 +327,17 @@ int gclm_merge_stop_at(gclm_handle* const* parts, float* const* d_info, const in
  * into partial records; only the summation order depends on it).  0 restores the built-in choice (20, fewer for
  * small batches).  Replaces the GCLM_SWEEP_ITERS environment variable of rounds 1-2: the solve reads no environment. */
 int gclm_set_sweep_iters(gclm_handle* h, int iters);
+
+/* sin(latitude_field) (lm_optimizer.py:262,270) does not depend on the parameters, yet each of the num_steps + 1 sweeps of
+ * a solve would re-evaluate it per pixel.  For the VALU-bound distortion models the first sweep of a solve therefore
+ * stores it in a LIBRARY-owned scratch plane (B x H x W floats inside the handle's workspace, grown on demand like the
+ * rest of it) and every later sweep reads that plane instead of `latitude_field`: same bytes read per sweep, one extra
+ * plane written per solve (1 / 105 of its traffic), same polynomial hence bit-identical results; the caller's boundary
+ * (float32 radians) does not change.
+ * mode -1 (default): the library decides (simple_radial / radial / simple_divisional with all five planes on the
+ * 16-byte-aligned path, at least one LM step, not the one-launch-per-step path; never pinhole, which is memory-bound);
+ * 0: never (saves B x H x W x 4 bytes of workspace); 1: wherever the sweep has the instantiation (also pinhole). */
+int gclm_set_slat_plane(gclm_handle* h, int mode);
 
 /* Small batches (the interactive single-image calibration of the reference's demo, interactive_demo.py:403) run ONE
  * launch per LM step: the per-image update of step k-1 is done in the prologue of every workgroup of sweep k

@@ -1,10 +1,12 @@
 """Instruction statistics of the sweep kernel's main loop (run in the build container: hipcc cross-compiles).
 
-usage: python scripts/isa_stats.py [--json OUT] [--dump SYMBOL_SUBSTRING] [MODEL ...]
+usage: python scripts/isa_stats.py [--json OUT] [--dump SYMBOL_SUBSTRING] [--slat 0|1|2] [MODEL ...]
        MODEL in {0 pinhole, 1 simple_radial, 2 radial, 3 simple_divisional}; default: all four.
 Looks at the instantiation sweep_kernel<MODEL, HAS_UP=1, HAS_UPC=1, HAS_LATC=1, LOGF=1, VEC=4> (the loop sweep of the
 default conf with both confidences: what bench.py runs) by its mangled template arguments, independent of how many
-template parameters precede / follow them.  EXTRA="-D..." adds compile flags (A/B switches of gclm_pass.hip)."""
+template parameters precede / follow them; --slat picks the SLAT instantiation (0: sin(latitude) computed per sweep, 1: computed
+and stored into the scratch plane = the first sweep of a solve, 2: loaded from it = every later sweep; gclm_pass.hip: row_math).
+EXTRA="-D..." adds compile flags (A/B switches of gclm_pass.hip)."""
 import collections
 import json
 import os
@@ -25,6 +27,9 @@ def main():
         i = args.index("--json"); out_json = args[i + 1]; del args[i:i + 2]
     if "--dump" in args:
         i = args.index("--dump"); dump = args[i + 1]; del args[i:i + 2]
+    slat = 0
+    if "--slat" in args:
+        i = args.index("--slat"); slat = int(args[i + 1]); del args[i:i + 2]
     models = [int(a) for a in args] or [0, 1, 2, 3]
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast-honor-pragmas",
                     "-fno-slp-vectorize", *os.environ.get("PASS_BASE_EXTRA", "-mllvm -disable-vector-combine").split(), *os.environ.get("EXTRA", "").split(), "-S", "--cuda-device-only", "-o", asm, src],
@@ -33,7 +38,7 @@ def main():
     results = {}
     for m_id in models:
         # sweep_kernel<MODEL, true, true, true, true(LOGF), 4(VEC)>
-        pat = r"^(_ZN4gclm\S*sweep_kernelILi%dELb1ELb1ELb1ELb1ELi4E\S*):\s*;.*?\n(.*?)\.amdhsa_kernel" % m_id
+        pat = r"^(_ZN4gclm\S*sweep_kernelILi%dELb1ELb1ELb1ELb1ELi4ELi%dE\S*):\s*;.*?\n(.*?)\.amdhsa_kernel" % (m_id, slat)
         m = re.search(pat, text, re.S | re.M)
         if not m:
             print(f"model {m_id}: instantiation not found (template signature changed?)")
@@ -91,7 +96,7 @@ def main():
             print("\n".join(body[a:b + 1]))
     if out_json:
         with open(out_json, "w") as fh:
-            json.dump({"kernel": "gclm::sweep_kernel<MODEL, up, up_conf, lat_conf, log-focal, float4>", "flags": os.environ.get("EXTRA", ""),
+            json.dump({"kernel": f"gclm::sweep_kernel<MODEL, up, up_conf, lat_conf, log-focal, float4, SLAT={slat}>", "flags": os.environ.get("EXTRA", ""),
                        "models": results}, fh, indent=1)
 
 
