@@ -21,6 +21,13 @@ def _outer(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return a[..., :, None] * b[..., None, :]
 
 
+def _one_of(pts, p2d):
+    """The positional / `pts=` argument or its `p2d=` alias (exactly one of them)."""
+    if (pts is None) == (p2d is None):
+        raise TypeError("pass the points once: positionally, as pts= or as p2d=")
+    return pts if p2d is None else p2d
+
+
 def _eye_like(p2d: torch.Tensor) -> torch.Tensor:
     return torch.eye(2, device=p2d.device, dtype=p2d.dtype).expand(p2d.shape[:-1] + (2, 2))
 
@@ -163,13 +170,17 @@ class BaseCamera(TensorWrapper):
     def check_valid(self, p2d: torch.Tensor) -> torch.Tensor:
         return p2d.new_ones(p2d.shape[:-1]).bool()
 
-    def distort(self, p2d: torch.Tensor, return_scale: bool = False):
+    # The reference names the argument `pts` on BaseCamera (camera.py:212,242) and `p2d` on the distortion models
+    # (camera.py:611,631,712,737,829,863); one body serves them all here, so both keywords are accepted.
+    def distort(self, pts: torch.Tensor = None, return_scale: bool = False, *, p2d: torch.Tensor = None):
         """Distort normalised coordinates; (scale, None) with return_scale."""
-        s = self._distort_scale((p2d**2).sum(-1, keepdim=True))
-        return (s, None) if return_scale else (p2d * s, self.check_valid(p2d))
+        pts = _one_of(pts, p2d)
+        s = self._distort_scale((pts**2).sum(-1, keepdim=True))
+        return (s, None) if return_scale else (pts * s, self.check_valid(pts))
 
-    def undistort(self, p2d: torch.Tensor):
-        return p2d * self._undistort_scale((p2d**2).sum(-1, keepdim=True)), self.check_valid(p2d)
+    def undistort(self, pts: torch.Tensor = None, *, p2d: torch.Tensor = None):
+        pts = _one_of(pts, p2d)
+        return pts * self._undistort_scale((pts**2).sum(-1, keepdim=True)), self.check_valid(pts)
 
     def J_distort(self, p2d: torch.Tensor, wrt: str = "pts") -> torch.Tensor:
         r2 = (p2d**2).sum(-1, keepdim=True)

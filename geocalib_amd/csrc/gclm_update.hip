@@ -625,160 +625,288 @@ __global__ void pack_fields_kernel(const float* __restrict__ up_raw, const float
 
 // ---------------------------------------------------------------- _post_process (the step after the path)
 // GeoCalib._post_process (extractor.py:51-69) brings the fields back to the input resolution with
-// F.interpolate(mode="bilinear", align_corners=False); one launch for any number of (h, w) planes.
+// F.interpolate(mode="bilinear", align_corners=False); one launch for any number of (h, w) planes of up to 8 tensors.
 // Source index as in ATen (area_pixel_compute_source_index): src = max(0, (dst + 0.5) * in/out - 0.5).
-// VEC = 4: one thread produces four horizontally adjacent output pixels (ONE 16-byte non-temporal store: the output is
-// the traffic, it is written once and read by a later kernel) of a row whose vertical taps it computes once; the 2 x 2
-// source taps per pixel are L1 / L2 hits (neighbouring threads share them).  32-bit index arithmetic, rows walked with an
-// incremental (row, unit) counter instead of a division per pixel.  VEC = 1: any width / alignment.
-template <int VEC>
+// Every path below evaluates, per output value and with these roundings,
+//     top/bot = fma(r[x0], 1 - lx, r[x1] * lx)        out = fma(top, 1 - ly, bot * ly)
+// so the scalar, gather and window kernels agree bit for bit (test_upsample_paths_agree_bitwise).
+__device__ __forceinline__ float up_src(int X, float scale) { return fmaxf(__fmaf_rn((float)X + 0.5f, scale, -0.5f), 0.f); }
+__device__ __forceinline__ float up_lerp(float a, float b, float l) { return __fmaf_rn(a, 1.f - l, __fmul_rn(b, l)); }
+
+// Scalar path: any width / alignment; one output value per thread and iteration, rows walked with an incremental
+// (row, column) counter instead of a division per pixel.
 __device__ __forceinline__ void upsample_plane(const float* __restrict__ s, float* __restrict__ d, int h, int w, int H, int W) {
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
-    const int Wu = W / VEC;                           // units per output row
-    const unsigned units = (unsigned)H * (unsigned)Wu;
+    const unsigned units = (unsigned)H * (unsigned)W;
     const unsigned stride = gridDim.x * blockDim.x;
-    const int dY = (int)(stride / (unsigned)Wu), dXu = (int)(stride - (unsigned)dY * (unsigned)Wu);
+    const int dY = (int)(stride / (unsigned)W), dX = (int)(stride - (unsigned)dY * (unsigned)W);
     unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
-    int Y = (int)(q / (unsigned)Wu), Xu = (int)(q - (unsigned)Y * (unsigned)Wu);
+    int Y = (int)(q / (unsigned)W), X = (int)(q - (unsigned)Y * (unsigned)W);
     for (; q < units; q += stride) {
-        const float fy = fmaxf(((float)Y + 0.5f) * sy - 0.5f, 0.f);
+        const float fy = up_src(Y, sy);
         const int y0 = min((int)fy, h - 1), y1 = min(y0 + 1, h - 1);
         const float ly = fy - (float)y0;
-        const float* r0 = s + y0 * w;
-        const float* r1 = s + y1 * w;
-        float o[VEC];
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            const int X = Xu * VEC + k;
-            const float fx = fmaxf(((float)X + 0.5f) * sx - 0.5f, 0.f);
-            const int x0 = min((int)fx, w - 1), x1 = min(x0 + 1, w - 1);
-            const float lx = fx - (float)x0;
-            const float top = r0[x0] * (1.f - lx) + r0[x1] * lx;
-            const float bot = r1[x0] * (1.f - lx) + r1[x1] * lx;
-            o[k] = top * (1.f - ly) + bot * ly;
-        }
-        if constexpr (VEC == 4) {
-            typedef float v4 __attribute__((ext_vector_type(4)));
-            __builtin_nontemporal_store(v4{o[0], o[1], o[2], o[3]}, reinterpret_cast<v4*>(d + (size_t)Y * W + Xu * 4));
-        } else {
-            d[(size_t)Y * W + Xu] = o[0];
-        }
-        Y += dY; Xu += dXu;
-        if (Xu >= Wu) { Xu -= Wu; ++Y; }
+        const float* r0 = s + (size_t)y0 * w;
+        const float* r1 = s + (size_t)y1 * w;
+        const float fx = up_src(X, sx);
+        const int x0 = min((int)fx, w - 1), x1 = min(x0 + 1, w - 1);
+        const float lx = fx - (float)x0;
+        d[(size_t)Y * W + X] = up_lerp(up_lerp(r0[x0], r0[x1], lx), up_lerp(r1[x0], r1[x1], lx), ly);
+        Y += dY; X += dX;
+        if (X >= W) { X -= W; ++Y; }
     }
 }
-template <int VEC>
-__global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __restrict__ src, int planes, int h, int w,
-                                                                  int H, int W, float* __restrict__ dst) {
-    for (int p = blockIdx.y; p < planes; p += gridDim.y)
-        upsample_plane<VEC>(src + (size_t)p * h * w, dst + (size_t)p * H * W, h, w, H, W);
-}
 
-// Tiled float4 variant (round 4).  The kernel above issues 16 scalar gathers per 16-byte store and ran at 2.0-2.4 TB/s, on
-// par with F.interpolate but far from the write bandwidth.  Here a WAVE owns a strip of 64 float4 units (256 output pixels)
-// and walks kUpRows consecutive output rows of it: the column terms (x0, x1, lx) are computed once per lane, the row terms
-// are wave-uniform, and the horizontally interpolated values of a SOURCE row are kept in registers and reused by every
-// output row that taps it (a 2x upsampling taps each source row from ~4 output rows): ~4 gathers per store instead of 16.
-// Same formulas per output value as upsample_plane.
-#ifndef GCLM_UPSAMPLE_PLAIN_STORE
-#define GCLM_UPSAMPLE_PLAIN_STORE 0      // A/B switch
-#endif
-#ifndef GCLM_UPSAMPLE_EXPERIMENT
-#define GCLM_UPSAMPLE_EXPERIMENT 0
-#endif
-constexpr int kUpRows = 8;
-template <bool WIDE>
-__device__ __forceinline__ void upsample_strip(const float* __restrict__ s, float* __restrict__ d, int h, int w, int H, int W,
-                                               int Xu, int Y0) {
+// float4 paths (W % 4 == 0, 16-byte aligned planes).  A WAVE owns 64 float4 units (256 output pixels, ONE 1 KiB
+// non-temporal store per output row: the output is the traffic, it is written once and read by a later kernel).
+//   * The wave index is made scalar (readfirstlane): row terms and the row-reuse branches are SALU, not exec-masked VALU.
+//   * WINDOW (upsampling by >= 1.5 horizontally, w >= 4): the eight taps of a lane's four pixels lie within FOUR consecutive
+//     source floats, so a source row costs ONE 16-byte load per lane (4-byte aligned) and the horizontal interpolation is
+//     a 5-term FMA chain over that window with per-lane weights -- 10 v_pk_fma_f32; round 4 used 24 v_cmp + 24 v_cndmask
+//     register selects.  Descending order makes the chain reproduce up_lerp exactly: every other term is an exact zero,
+//     the last non-zero term fused is the x0 tap; E carries the clamped right edge (x1 == x0, both weights on t.w).
+//   * Position q of a row maps to unit (q + o) mod Wu, o = the units from the row's first byte up to the next 128-byte
+//     line: every full wave store then starts on a line.  Rows of 1620 floats (6480 B) are not whole lines; round 4
+//     wrote each wave's 1 KiB across nine lines, two of them partial, and the stores alone took 1.75x a flat fill
+//     (profiles/r05_upsample_bench.log: 652 -> 439 us for 64 x 5 planes 320x480 -> 1080x1620).
+//   * CONSEC (rows are whole lines, Wu % 8 == 0): a wave walks ROWS consecutive output rows; every source row it needs is
+//     loaded up front (PREF, when the vertical ratio bounds their number) and its horizontally interpolated values stay in
+//     registers for all output rows that tap it.
+//   * PHASED (ragged rows): rows 8 apart share the phase o (8 Wu = 0 mod 8 units), so wave i of a 512-thread block owns
+//     rows Y0 + i + 8 j and keeps its column weights; all 2 ROWS window loads are issued before the arithmetic.
+//   * GATHER (any other ratio): per-lane dword gathers, consecutive rows, no rotation.
+typedef float up_v2 __attribute__((ext_vector_type(2)));
+typedef float up_v4 __attribute__((ext_vector_type(4)));
+typedef float up_v4u __attribute__((ext_vector_type(4), aligned(4)));
+struct UpCol {
+    int xs, u;              // window start (source floats), output unit of this lane
+    up_v2 W[4][2], E[2];    // weight of window float j for the outputs (0, 1) and (2, 3)
+    bool live;
+};
+__device__ __forceinline__ UpCol up_col_weights(int q, int o, int w, int W, float sx) {
+    UpCol c;
+    const int Wu = W >> 2;
+    int u = q + (Wu >= 64 ? o : 0);      // rows shorter than one wave store: nothing to align
+    if (u >= Wu) u -= Wu;
+    c.live = q < Wu;
+    if (!c.live) u = 0;
+    c.u = u;
+    int x0[4], x1[4];
+    float lx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float fx = up_src(u * 4 + k, sx);
+        x0[k] = min((int)fx, w - 1);
+        x1[k] = min(x0[k] + 1, w - 1);
+        lx[k] = fx - (float)x0[k];
+    }
+    c.xs = min(x0[0], w - 4);
+    float Wm[4][4], Em[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i0 = x0[k] - c.xs, i1 = x1[k] - c.xs;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Wm[j][k] = (j == i1) ? lx[k] : ((j == i0) ? 1.f - lx[k] : 0.f);
+        Em[k] = (i0 == i1) ? 1.f - lx[k] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { c.W[j][0] = up_v2{Wm[j][0], Wm[j][1]}; c.W[j][1] = up_v2{Wm[j][2], Wm[j][3]}; }
+    c.E[0] = up_v2{Em[0], Em[1]}; c.E[1] = up_v2{Em[2], Em[3]};
+    return c;
+}
+__device__ __forceinline__ void up_hwindow(const UpCol& c, const up_v4u& t, up_v2 (&o)[2]) {
+#pragma unroll
+    for (int hlf = 0; hlf < 2; ++hlf) {
+        up_v2 a = up_v2{t.w, t.w} * c.W[3][hlf];
+        a = __builtin_elementwise_fma(up_v2{t.w, t.w}, c.E[hlf], a);
+        a = __builtin_elementwise_fma(up_v2{t.z, t.z}, c.W[2][hlf], a);
+        a = __builtin_elementwise_fma(up_v2{t.y, t.y}, c.W[1][hlf], a);
+        a = __builtin_elementwise_fma(up_v2{t.x, t.x}, c.W[0][hlf], a);
+        o[hlf] = a;
+    }
+}
+struct UpRow { int y0, y1; float ly; };
+__device__ __forceinline__ UpRow up_row_terms(int Y, int h, float sy) {      // Y wave-uniform: the results are scalars
+    const float fy = up_src(Y, sy);
+    const int y0 = min((int)fy, h - 1);
+    UpRow r;
+    r.ly = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, fy - (float)y0)));
+    r.y0 = __builtin_amdgcn_readfirstlane(y0);
+    r.y1 = min(r.y0 + 1, h - 1);
+    return r;
+}
+__device__ __forceinline__ void up_vblend_store(float* p, bool live, float ly, const up_v2 (&ha)[2], const up_v2 (&hb)[2]) {
+    const up_v2 l2 = up_v2{ly, ly}, m2 = up_v2{1.f - ly, 1.f - ly};
+    const up_v2 o0 = __builtin_elementwise_fma(ha[0], m2, hb[0] * l2), o1 = __builtin_elementwise_fma(ha[1], m2, hb[1] * l2);
+    if (live) __builtin_nontemporal_store(up_v4{o0.x, o0.y, o1.x, o1.y}, reinterpret_cast<up_v4*>(p));
+}
+__device__ __forceinline__ unsigned up_line_unit(const float* d) { return (unsigned)((reinterpret_cast<uintptr_t>(d) >> 4) & 7u); }
+
+template <int ROWS, bool PREF>
+__device__ __forceinline__ void upsample_consec(const float* __restrict__ s, float* __restrict__ d, int h, int w, int H, int W, int q,
+                                                int Y0) {
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    const UpCol c = up_col_weights(q, (int)((8u - up_line_unit(d)) & 7u), w, W, sx);
+    const int Yend = min(Y0 + ROWS, H);
+    const float* sc = s + c.xs;
+    float* dc = d + c.u * 4;
+    if constexpr (PREF) {      // 3 h <= 2 H: rows Y0 .. Y0 + ROWS - 1 tap at most 2 ROWS / 3 + 3 source rows
+        constexpr int RMAX = 2 * ROWS / 3 + 3;
+        const UpRow ra = up_row_terms(Y0, h, sy), rb = up_row_terms(Yend - 1, h, sy);
+        const int ylo = ra.y0, yhi = rb.y1, n = yhi - ylo + 1;
+        up_v4u t[RMAX];
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) t[r] = *reinterpret_cast<const up_v4u*>(sc + (size_t)min(ylo + r, yhi) * w);
+        up_v2 hc[2], hn[2];
+        up_hwindow(c, t[0], hc);
+        int Y = Y0;
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            if (r < n) {
+                if (r + 1 < RMAX && r + 1 < n) up_hwindow(c, t[r + 1 < RMAX ? r + 1 : r], hn);
+                else { hn[0] = hc[0]; hn[1] = hc[1]; }        // y1 == y0: the last source row
+                while (Y < Yend) {
+                    const UpRow rt = up_row_terms(Y, h, sy);
+                    if (rt.y0 - ylo != r) break;
+                    up_vblend_store(dc + (size_t)Y * W, c.live, rt.ly, hc, hn);
+                    ++Y;
+                }
+                hc[0] = hn[0]; hc[1] = hn[1];
+            }
+        }
+    } else {
+        int ya = -1, yb = -1;
+        up_v2 ha[2] = {up_v2{0.f, 0.f}, up_v2{0.f, 0.f}}, hb[2] = {up_v2{0.f, 0.f}, up_v2{0.f, 0.f}};
+        for (int Y = Y0; Y < Yend; ++Y) {
+            const UpRow rt = up_row_terms(Y, h, sy);
+            if (!(rt.y0 == ya && rt.y1 == yb)) {
+                if (rt.y0 == yb) { ha[0] = hb[0]; ha[1] = hb[1]; }
+                else if (rt.y0 != ya) up_hwindow(c, *reinterpret_cast<const up_v4u*>(sc + (size_t)rt.y0 * w), ha);
+                ya = rt.y0;
+                if (rt.y1 == rt.y0) { hb[0] = ha[0]; hb[1] = ha[1]; }
+                else up_hwindow(c, *reinterpret_cast<const up_v4u*>(sc + (size_t)rt.y1 * w), hb);
+                yb = rt.y1;
+            }
+            up_vblend_store(dc + (size_t)Y * W, c.live, rt.ly, ha, hb);
+        }
+    }
+}
+template <int ROWS>
+__device__ __forceinline__ void upsample_phased(const float* __restrict__ s, float* __restrict__ d, int h, int w, int H, int W, int q,
+                                                int Ya) {
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    const unsigned g = up_line_unit(d) + (unsigned)Ya * (unsigned)(W >> 2);      // the row's first unit, mod 8 = its phase
+    const UpCol c = up_col_weights(q, (int)((8u - (g & 7u)) & 7u), w, W, sx);
+    const float* sc = s + c.xs;
+    float* dc = d + c.u * 4;
+    up_v4u ta[ROWS], tb[ROWS];
+    UpRow rt[ROWS];
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        rt[j] = up_row_terms(min(Ya + 8 * j, H - 1), h, sy);
+        ta[j] = *reinterpret_cast<const up_v4u*>(sc + (size_t)rt[j].y0 * w);
+        tb[j] = *reinterpret_cast<const up_v4u*>(sc + (size_t)rt[j].y1 * w);
+    }
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        up_v2 ha[2], hb[2];
+        up_hwindow(c, ta[j], ha);
+        up_hwindow(c, tb[j], hb);
+        const int Y = Ya + 8 * j;
+        up_vblend_store(dc + (size_t)Y * W, c.live && Y < H, rt[j].ly, ha, hb);
+    }
+}
+template <int ROWS>
+__device__ __forceinline__ void upsample_gather(const float* __restrict__ s, float* __restrict__ d, int h, int w, int H, int W, int Xu,
+                                                int Y0) {
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
     const bool live = Xu * 4 < W;
     int x0[4], x1[4];
     float lx[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int X = min(Xu * 4 + k, W - 1);
-        const float fx = fmaxf(((float)X + 0.5f) * sx - 0.5f, 0.f);
+        const float fx = up_src(min(Xu * 4 + k, W - 1), sx);
         x0[k] = min((int)fx, w - 1);
         x1[k] = min(x0[k] + 1, w - 1);
         lx[k] = fx - (float)x0[k];
     }
-    // WIDE (upsampling by >= 1.5, i.e. sx <= 2/3, and w >= 4): the eight taps of a lane's four pixels lie within FOUR
-    // consecutive source floats, so a source row costs ONE 16-byte load per lane (4-byte aligned) and eight register
-    // selects instead of eight dword gathers -- a stride-2 dword gather was measured at ~25 cycles of a CU's address
-    // unit apiece, and gathers and stores share that unit (no-gather build 0.30 ms + no-store build 0.32 ms = 0.63 ms).
-    const int xs = min(x0[0], w - 4);
-    int i0[4], i1[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { i0[k] = x0[k] - xs; i1[k] = x1[k] - xs; }
-    auto pick = [](const float (&t)[4], int i) { return i == 0 ? t[0] : (i == 1 ? t[1] : (i == 2 ? t[2] : t[3])); };
     auto hrow = [&](int y, float (&o)[4]) {
         const float* r = s + (size_t)y * w;
-        if constexpr (WIDE) {
-            typedef float v4u __attribute__((ext_vector_type(4), aligned(4)));
-            const v4u q = *reinterpret_cast<const v4u*>(r + xs);
-            const float t[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = pick(t, i0[k]) * (1.f - lx[k]) + pick(t, i1[k]) * lx[k];
-            return;
-        }
-#if GCLM_UPSAMPLE_EXPERIMENT == 1      // measurement only: no gathers (what do index math + stores cost?)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = (float)(y + x0[k]) * (1.f - lx[k]) + (float)x1[k] * lx[k];
-        (void)r;
-#else
-#pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = r[x0[k]] * (1.f - lx[k]) + r[x1[k]] * lx[k];
-#endif
+        for (int k = 0; k < 4; ++k) o[k] = up_lerp(r[x0[k]], r[x1[k]], lx[k]);
     };
     int ya = -1, yb = -1;
     float ha[4] = {0.f, 0.f, 0.f, 0.f}, hb[4] = {0.f, 0.f, 0.f, 0.f};
-    const int Yend = min(Y0 + kUpRows, H);
-    for (int Y = Y0; Y < Yend; ++Y) {                 // wave-uniform trip count and row terms
-        const float fy = fmaxf(((float)Y + 0.5f) * sy - 0.5f, 0.f);
-        const int y0 = min((int)fy, h - 1), y1 = min(y0 + 1, h - 1);
-        const float ly = fy - (float)y0;
-        if (!(y0 == ya && y1 == yb)) {
-            if (y0 == yb) {
+    const int Yend = min(Y0 + ROWS, H);
+    for (int Y = Y0; Y < Yend; ++Y) {
+        const UpRow rt = up_row_terms(Y, h, sy);
+        if (!(rt.y0 == ya && rt.y1 == yb)) {
+            if (rt.y0 == yb) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) ha[k] = hb[k];
-            } else if (y0 != ya) {
-                hrow(y0, ha);
+            } else if (rt.y0 != ya) {
+                hrow(rt.y0, ha);
             }
-            ya = y0;
-            if (y1 == y0) {
+            ya = rt.y0;
+            if (rt.y1 == rt.y0) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) hb[k] = ha[k];
             } else {
-                hrow(y1, hb);
+                hrow(rt.y1, hb);
             }
-            yb = y1;
+            yb = rt.y1;
         }
-#if GCLM_UPSAMPLE_EXPERIMENT == 2          // measurement only: no stores (what do the gathers + math cost?)
-        if (live && ha[0] * (1.f - ly) + hb[0] * ly == 1.2345e30f) {
-#else
-        if (live) {
-#endif
-            typedef float v4 __attribute__((ext_vector_type(4)));
-            const v4 o = {ha[0] * (1.f - ly) + hb[0] * ly, ha[1] * (1.f - ly) + hb[1] * ly, ha[2] * (1.f - ly) + hb[2] * ly,
-                          ha[3] * (1.f - ly) + hb[3] * ly};
-#if GCLM_UPSAMPLE_PLAIN_STORE
-            *reinterpret_cast<v4*>(d + (size_t)Y * W + Xu * 4) = o;
-#else
-            __builtin_nontemporal_store(o, reinterpret_cast<v4*>(d + (size_t)Y * W + Xu * 4));
-#endif
+        if (live)
+            __builtin_nontemporal_store(up_v4{up_lerp(ha[0], hb[0], rt.ly), up_lerp(ha[1], hb[1], rt.ly), up_lerp(ha[2], hb[2], rt.ly),
+                                              up_lerp(ha[3], hb[3], rt.ly)},
+                                        reinterpret_cast<up_v4*>(d + (size_t)Y * W + Xu * 4));
+    }
+}
+
+// grid = (strips of 64 units, row groups, planes of all tensors); blockIdx.z strides over the planes beyond 65 535
+struct UpPlane { const float* s; float* d; };
+__device__ __forceinline__ UpPlane up_plane(const UpsampleMulti& m, int P, int h, int w, int H, int W) {
+    int t = 0;
+    while (t < m.n - 1 && P >= m.planes[t]) { P -= m.planes[t]; ++t; }
+    return UpPlane{m.src[t] + (size_t)P * h * w, m.dst[t] + (size_t)P * H * W};
+}
+enum { kUpScalar = 0, kUpGather = 1, kUpConsec = 2, kUpConsecPref = 3, kUpPhased = 4 };
+template <int MODE, int ROWS>
+__global__ __launch_bounds__(MODE == kUpPhased ? 512 : 256) void upsample_kernel(UpsampleMulti m, int total, int h, int w, int H, int W) {
+    if constexpr (MODE == kUpScalar) {
+        for (int P = blockIdx.y; P < total; P += gridDim.y) {
+            const UpPlane pl = up_plane(m, P, h, w, H, W);
+            upsample_plane(pl.s, pl.d, h, w, H, W);
+        }
+    } else {
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int q = blockIdx.x * 64 + (threadIdx.x & 63);
+        const int Y0 = MODE == kUpPhased ? blockIdx.y * (8 * ROWS) + wave : (blockIdx.y * 4 + wave) * ROWS;
+        if (Y0 >= H) return;
+        for (int P = blockIdx.z; P < total; P += gridDim.z) {
+            const UpPlane pl = up_plane(m, P, h, w, H, W);
+            if constexpr (MODE == kUpGather) upsample_gather<ROWS>(pl.s, pl.d, h, w, H, W, q, Y0);
+            else if constexpr (MODE == kUpPhased) upsample_phased<ROWS>(pl.s, pl.d, h, w, H, W, q, Y0);
+            else upsample_consec<ROWS, MODE == kUpConsecPref>(pl.s, pl.d, h, w, H, W, q, Y0);
         }
     }
 }
-// grid = (strips of 64 units, blocks of 4 waves x kUpRows rows, planes); one wave per (strip, row group)
-template <bool WIDE>
-__global__ __launch_bounds__(256) void upsample_tiled_kernel(const float* __restrict__ src, int planes, int h, int w, int H, int W,
-                                                             float* __restrict__ dst) {
-    const int Xu = blockIdx.x * 64 + (threadIdx.x & 63), Y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * kUpRows;
-    for (int p = blockIdx.z; p < planes; p += gridDim.z)
-        upsample_strip<WIDE>(src + (size_t)p * h * w, dst + (size_t)p * H * W, h, w, H, W, Xu, Y0);
+// The four-float window holds every tap of four adjacent output pixels when x0[3] <= x0[0] + 2, i.e. 3 sx <= 2 in exact
+// arithmetic.  The kernel derives x0 from fp32 (X + 0.5) sx - 0.5, whose error per value is below fx 2^-23 <= w 2^-23;
+// two of them must not bridge the gap 2 - 3 w / W = (2 W - 3 w) / W, so away from the exact ratio 1.5 (where no source
+// coordinate of a lane's first pixel is an integer: (16 u - 1) / 6) the window path needs (2 W - 3 w) 2^21 > w W.
+__host__ inline bool upsample_window_ok(int w, int W) {
+    const long long gap = 2LL * W - 3LL * w;
+    return w >= 4 && (gap == 0 || (gap > 0 && (double)gap * 2097152.0 > (double)w * (double)W));
 }
-// the four-float window holds every tap of four adjacent output pixels: x0[3] <= x0[0] + ceil(3 sx) <= x0[0] + 2
-__host__ inline bool upsample_wide_ok(int w, int W) { return w >= 4 && 3LL * w <= 2LL * W; }
+__host__ inline int upsample_mode(const UpsampleMulti& m, int h, int w, int H, int W) {
+    bool vec4 = W % 4 == 0;
+    for (int t = 0; t < m.n; ++t) vec4 = vec4 && (reinterpret_cast<uintptr_t>(m.dst[t]) & 15u) == 0;
+    if (!vec4) return kUpScalar;
+    if (!upsample_window_ok(w, W)) return kUpGather;
+    if ((W / 4) % 8 != 0) return kUpPhased;
+    return 3LL * h <= 2LL * H ? kUpConsecPref : kUpConsec;
+}
 
 // optimizer_step (lm_optimizer.py:109-137) as a batched device kernel: delta = (H + diag(clamp(lambda diag H, eps)))^-1 G
 // by an fp32 Cholesky per system (the reference copies H, G to the CPU for this, twice per LM step).  A system
@@ -956,54 +1084,45 @@ hipError_t launch_pblock_from_params(const SolveCtx& c, const float* d_cam, cons
     return hipGetLastError();
 }
 // Several tensors of (h, w) planes in ONE launch (the four tensors _post_process resizes: up 2 planes per image, latitude,
-// two confidences): a single-image calibrate() pays one launch instead of four.  grid.y walks the planes of all tensors.
-__global__ __launch_bounds__(256) void upsample_scalar_multi_kernel(UpsampleMulti m, int h, int w, int H, int W) {
-    int p = blockIdx.y, t = 0;
-    while (t < m.n - 1 && p >= m.planes[t]) { p -= m.planes[t]; ++t; }
-    upsample_plane<1>(m.src[t] + (size_t)p * h * w, m.dst[t] + (size_t)p * H * W, h, w, H, W);
-}
-template <bool WIDE>
-__global__ __launch_bounds__(256) void upsample_tiled_multi_kernel(UpsampleMulti m, int h, int w, int H, int W) {
-    int p = blockIdx.z, t = 0;
-    while (t < m.n - 1 && p >= m.planes[t]) { p -= m.planes[t]; ++t; }
-    const int Xu = blockIdx.x * 64 + (threadIdx.x & 63), Y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * kUpRows;
-    upsample_strip<WIDE>(m.src[t] + (size_t)p * h * w, m.dst[t] + (size_t)p * H * W, h, w, H, W, Xu, Y0);
+// two confidences): a single-image calibrate() pays one launch instead of four.  Small jobs (one image) take half the
+// rows per wave: twice the waves to fill 256 CUs.
+template <int MODE>
+static void launch_upsample_mode(const UpsampleMulti& m, int total, int h, int w, int H, int W, bool small, hipStream_t s) {
+    const int strips = (W / 4 + 63) / 64, gz = total < 65535 ? total : 65535;
+    if (small) {
+        constexpr int R = 4;
+        const dim3 grid(strips, MODE == kUpPhased ? (H + 8 * R - 1) / (8 * R) : (H + 4 * R - 1) / (4 * R), gz);
+        hipLaunchKernelGGL((upsample_kernel<MODE, R>), grid, dim3(MODE == kUpPhased ? 512 : 256), 0, s, m, total, h, w, H, W);
+    } else {
+        constexpr int R = 8;
+        const dim3 grid(strips, MODE == kUpPhased ? (H + 8 * R - 1) / (8 * R) : (H + 4 * R - 1) / (4 * R), gz);
+        hipLaunchKernelGGL((upsample_kernel<MODE, R>), grid, dim3(MODE == kUpPhased ? 512 : 256), 0, s, m, total, h, w, H, W);
+    }
 }
 hipError_t launch_upsample_multi(const UpsampleMulti& m, int h, int w, int H, int W, hipStream_t s) {
-    int total = 0;
-    bool vec4 = W % 4 == 0;
-    for (int t = 0; t < m.n; ++t) {
-        total += m.planes[t];
-        vec4 = vec4 && (reinterpret_cast<uintptr_t>(m.dst[t]) & 15u) == 0 && ((size_t)H * W) % 4 == 0;
-    }
+    long long total = 0;
+    for (int t = 0; t < m.n; ++t) total += m.planes[t];
     if (total == 0 || (size_t)H * W == 0) return hipSuccess;
-    if (total > 65535) return hipErrorInvalidValue;
-    if (vec4) {
-        const dim3 grid((W / 4 + 63) / 64, (H + 4 * kUpRows - 1) / (4 * kUpRows), total);
-        if (upsample_wide_ok(w, W)) hipLaunchKernelGGL(upsample_tiled_multi_kernel<true>, grid, dim3(256), 0, s, m, h, w, H, W);
-        else hipLaunchKernelGGL(upsample_tiled_multi_kernel<false>, grid, dim3(256), 0, s, m, h, w, H, W);
-    } else {
-        unsigned bx = ((unsigned)H * (unsigned)W + 256 * 4 - 1) / (256 * 4);
-        hipLaunchKernelGGL(upsample_scalar_multi_kernel, dim3(bx < 1 ? 1 : bx, total), dim3(256), 0, s, m, h, w, H, W);
+    if (total > 0x7fffffffLL) return hipErrorInvalidValue;
+    const bool small = (double)total * H * W < 16.0e6;
+    switch (upsample_mode(m, h, w, H, W)) {
+        case kUpScalar: {
+            unsigned bx = ((unsigned)H * (unsigned)W + 256 * 4 - 1) / (256 * 4);
+            hipLaunchKernelGGL((upsample_kernel<kUpScalar, 1>), dim3(bx < 1 ? 1 : bx, (unsigned)(total < 65535 ? total : 65535)), dim3(256), 0, s, m,
+                               (int)total, h, w, H, W);
+            break;
+        }
+        case kUpGather: launch_upsample_mode<kUpGather>(m, (int)total, h, w, H, W, small, s); break;
+        case kUpConsec: launch_upsample_mode<kUpConsec>(m, (int)total, h, w, H, W, small, s); break;
+        case kUpConsecPref: launch_upsample_mode<kUpConsecPref>(m, (int)total, h, w, H, W, small, s); break;
+        default: launch_upsample_mode<kUpPhased>(m, (int)total, h, w, H, W, small, s); break;
     }
     return hipGetLastError();
 }
 hipError_t launch_upsample(const float* src, int planes, int h, int w, int H, int W, float* dst, hipStream_t s) {
-    if ((size_t)planes * H * W == 0) return hipSuccess;
-    const bool vec4 = W % 4 == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;
-    const unsigned units = (unsigned)H * (unsigned)(vec4 ? W / 4 : W);
-    // ~4 units per thread and plane; planes on grid.y (strided beyond 65 535)
-    unsigned bx = (units + 256 * 4 - 1) / (256 * 4);
-    if (bx < 1) bx = 1;
-    const dim3 grid(bx, planes < 65535 ? planes : 65535), block(256);
-    if (vec4) {
-        const dim3 tgrid((W / 4 + 63) / 64, (H + 4 * kUpRows - 1) / (4 * kUpRows), planes < 65535 ? planes : 65535);
-        if (upsample_wide_ok(w, W)) hipLaunchKernelGGL(upsample_tiled_kernel<true>, tgrid, block, 0, s, src, planes, h, w, H, W, dst);
-        else hipLaunchKernelGGL(upsample_tiled_kernel<false>, tgrid, block, 0, s, src, planes, h, w, H, W, dst);
-    } else {
-        hipLaunchKernelGGL(upsample_bilinear_kernel<1>, grid, block, 0, s, src, planes, h, w, H, W, dst);
-    }
-    return hipGetLastError();
+    UpsampleMulti m{};
+    m.src[0] = src; m.dst[0] = dst; m.planes[0] = planes; m.n = 1;
+    return launch_upsample_multi(m, h, w, H, W, s);
 }
 
 hipError_t launch_pack_fields(const float* up_raw, const float* up_lc, const float* lat_raw, const float* lat_lc,

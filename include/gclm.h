@@ -209,7 +209,7 @@ int gclm_pack_fields(const float* d_up_raw, const float* d_up_logconf, const flo
  */
 int gclm_upsample_fields(const float* d_src, int planes, int h, int w, int H, int W, float* d_dst, void* stream);
 /* ... and the same for up to 8 tensors of (h, w) planes in ONE launch (the four tensors _post_process resizes: a
- * single-image calibrate() pays one launch instead of four); at most 65 535 planes in total. */
+ * single-image calibrate() pays one launch instead of four). */
 int gclm_upsample_fields_multi(const float* const* d_srcs, float* const* d_dsts, const int* planes, int n_tensors, int h, int w,
                                int H, int W, void* stream);
 

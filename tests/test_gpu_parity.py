@@ -953,7 +953,14 @@ def test_randomised_configurations_against_oracle(dev, oracle):
                                    ((2, 1, 90, 120), (100, 160)),       # x1.33 in x: tiled, but the four-float window does not hold
                                    ((1, 2, 37, 52), (111, 208)),        # x4 in x, x3 in y
                                    ((2, 7, 3), (20, 12)), ((1, 5, 4), (9, 8)),      # sources narrower than / exactly one window
-                                   ((2, 64, 80), (32, 40))])            # downsampling through the float4 path
+                                   ((2, 64, 80), (32, 40)),             # downsampling through the float4 path
+                                   ((11, 5, 240, 320), (480, 640)),     # rows of whole lines, 8 rows per wave, source rows prefetched
+                                   ((2, 5, 320, 480), (1080, 1620)),    # ragged rows (6480 B): phase-rotated units, 8 rows per wave
+                                   ((1, 5, 320, 480), (1080, 1620)),    # ... one image: 4 rows per wave
+                                   ((3, 9, 12), (27, 36)),              # ragged rows AND ragged planes (3888 B): a phase per plane
+                                   ((2, 100, 64), (120, 160)),          # window in x, x1.2 in y: no prefetch of the source rows
+                                   ((1, 8, 2048), (8, 3072)),           # exactly x1.5 on a wide row: the window path
+                                   ((1, 8, 2730), (16, 4096))])         # a hair under x1.5 at 4096 wide: fp32 cannot promise the window
 def test_upsample_fields_matches_torch_interpolate(dev, shape):
     """gclm_upsample_fields (GeoCalib._post_process, extractor.py:60-63) against F.interpolate bilinear."""
     from geocalib_amd.fields import upsample_fields
@@ -964,6 +971,42 @@ def test_upsample_fields_matches_torch_interpolate(dev, shape):
     out = upsample_fields(x, size)
     assert out.shape == ref.shape
     assert torch.allclose(out, ref, atol=2e-6, rtol=1e-6), (out - ref).abs().max().item()
+
+
+def test_upsample_paths_agree_bitwise(dev):
+    """The scalar, gather, consecutive-row and phase-rotated kernels of gclm_upsample_fields evaluate the same roundings per
+    output value (csrc/gclm_update.hip: up_lerp): a 4-byte shifted destination forces the scalar kernel, which every float4
+    path must reproduce bit for bit."""
+    from geocalib_amd import _lib
+    lib = _lib.load()
+    for (planes, h, w), (H, W) in (((10, 240, 320), (480, 640)), ((56, 240, 320), (480, 640)), ((3, 320, 480), (1080, 1620)),
+                                   ((11, 320, 480), (1080, 1620)), ((3, 90, 120), (100, 160)), ((2, 100, 64), (120, 160)),
+                                   ((4, 9, 12), (27, 36)), ((1, 8, 2730), (16, 4096)), ((1, 8, 2048), (8, 3072))):
+        x = torch.randn(planes, h, w, generator=torch.Generator().manual_seed(planes)).to(dev)
+        vec = torch.full((planes * H * W,), float("nan"), device=dev)
+        sca = torch.full((planes * H * W + 4,), float("nan"), device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        assert lib.gclm_upsample_fields(x.data_ptr(), planes, h, w, H, W, vec.data_ptr(), stream) == 0
+        assert lib.gclm_upsample_fields(x.data_ptr(), planes, h, w, H, W, sca.data_ptr() + 4, stream) == 0
+        torch.cuda.synchronize()
+        assert torch.isnan(sca[0]) and torch.isnan(sca[-3:]).all()
+        assert torch.equal(vec, sca[1:-3]), ((planes, h, w), (H, W), (vec - sca[1:-3]).abs().max().item())
+
+
+def test_upsample_multi_ragged_planes(dev):
+    """gclm_upsample_fields_multi on tensors whose planes are not whole 128-byte lines: the store rotation takes its phase
+    from every plane's own address."""
+    import torch.nn.functional as F
+    from geocalib_amd.fields import upsample_fields_multi
+    g = torch.Generator().manual_seed(5)
+    for (h, w), size in (((9, 12), (27, 36)), ((320, 480), (1080, 1620)), ((240, 320), (480, 640))):
+        ts = [torch.randn(2, 2, h, w, generator=g).to(dev), torch.randn(2, h, w, generator=g).to(dev),
+              torch.randn(2, 1, h, w, generator=g).to(dev), torch.randn(2, h, w, generator=g).to(dev)]
+        outs = upsample_fields_multi(ts, size)
+        for t, o in zip(ts, outs):
+            ref = F.interpolate(t if t.dim() == 4 else t[:, None], size=size, mode="bilinear")
+            ref = ref if t.dim() == 4 else ref[:, 0]
+            assert o.shape == ref.shape and torch.allclose(o, ref, atol=2e-6, rtol=1e-6), (o - ref).abs().max().item()
 
 
 def test_calibrate_front_end(dev):
