@@ -53,12 +53,16 @@ def main():
     fuzz = collections.defaultdict(lambda: {"draws": 0, "undetermined": 0, "gated": 0, "by_yardstick": collections.Counter(),
                                             "worst": [0, 0, 0, 0], "worst_over_gate": 0.0, "beyond_gate_on_unstable_yardstick": []})
     for label, v in rec.items():
-        if not label.startswith("fuzz/"):
+        if not label.startswith("fuzz/"):      # ("fuzz_summary/<seed>" is the test's own tally; recomputed here)
             continue
         f = fuzz[(label.split("/")[1], v["model"])]
         f["draws"] += 1
         if v.get("undetermined"):
             f["undetermined"] += 1
+            if "first_step_spread" in v:          # compared after ONE LM step instead (round 5)
+                f["undetermined_compared_at_first_step"] = f.get("undetermined_compared_at_first_step", 0) + 1
+                f["first_step_worst_over_gate"] = max(f.get("first_step_worst_over_gate", 0.0),
+                                                      max(s / t for s, t in zip(v["first_step_spread"], v["first_step_tol"])))
             continue
         if v.get("excused"):             # beyond its gate, and the oracle's own float32 evaluation shown unstable on the draw
             f["beyond_gate_on_unstable_yardstick"].append({"case": label, "spread": v["spread"], "gate": v["tol"], "diagnosis": v["excused"]})
@@ -69,7 +73,9 @@ def main():
         f["worst_over_gate"] = max(f["worst_over_gate"], max(s / t for s, t in zip(v["spread"], v["tol"])))
     fz = {}
     for (seed, m), f in sorted(fuzz.items()):
-        fz.setdefault(seed, {})[m] = {**f, "by_yardstick": dict(f["by_yardstick"])}
+        fz.setdefault(seed, {})[m] = {**f, "by_yardstick": dict(f["by_yardstick"]),
+                                      "fraction_compared_at_the_end": round(1.0 - f["undetermined"] / max(f["draws"], 1), 3),
+                                      "fraction_compared_at_all": round(1.0 - (f["undetermined"] - f.get("undetermined_compared_at_first_step", 0)) / max(f["draws"], 1), 3)}
     out = {"what": "worst HIP-vs-yardstick distance per camera model, as recorded by the -m gpu suite on an MI355X "
                    "(focal: relative; dist, gravity: absolute; cost, cov, unc: relative to the largest entry); gate = the "
                    "tolerance the worst case was held to", "goldens_and_oracle": table,

@@ -3,9 +3,12 @@
     python tests/golden/make_golden_full_rd.py        (build container only: needs /root/reference)
 
 `radial` (k1, k2; camera.py:663-786) and `simple_divisional` (camera.py:789-942), two seeded images each, run through
-the reference's own LMOptimizer (CPU float32, eval, no_grad).  For `simple_divisional` the reference's 1-ulp input
-sensitivity is stored too (see make_golden_div.py): the gate of the tests is [..] + 10 x spread.  Inputs are regenerated
-from the seed by the tests; only outputs and an input checksum are stored (golden_full_rd.npz)."""
+the reference's own LMOptimizer (CPU float32, eval, no_grad).  The reference's 1-ulp input sensitivity is stored too
+(see make_golden_div.py): `spread` (the gate of the tests is [..] + 10 x spread) and `stop_at_set`, the values the
+reference's OWN `stop_at` takes over the unperturbed run and N_PERTURB perturbed ones -- `stop_at` is the first step at
+which every cost has stopped moving by 1e-8, a threshold crossing; the test gates the HIP path's `stop_at` by the range
+this set spans instead of an asserted +-1.  Inputs are regenerated from the seed by the tests; only outputs and an input
+checksum are stored (golden_full_rd.npz)."""
 import os
 import sys
 
@@ -21,6 +24,7 @@ from make_golden_div import perturbed, run  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SEED, FULL = 1234, (480, 640)
+N_PERTURB = 8
 INDICES = {"radial": (0, 1), "simple_divisional": (2, 5)}
 BENCH = {"num_steps": 20, "early_stop": False}
 
@@ -41,12 +45,16 @@ def main():
         out[f"{model}/gt_camera"], out[f"{model}/gt_gravity"] = cams, gravs
         base = run(ref, conf, data)
         rng = np.random.default_rng([SEED, 77])
-        spread = np.zeros(4)
-        for _ in range(2):
-            spread = np.maximum(spread, result_spread(run(ref, conf, perturbed(data, rng)), base))
+        spread, stops = np.zeros(4), [base["stop_at"]]
+        for i in range(N_PERTURB):
+            moved = run(ref, conf, perturbed(data, rng))
+            if i < 2:               # `spread` as in round 3 (two perturbations, same generator state)
+                spread = np.maximum(spread, result_spread(moved, base))
+            stops.append(moved["stop_at"])
         out[f"{model}/spread"] = spread
+        out[f"{model}/stop_at_set"] = np.unique(np.concatenate([np.asarray(v).ravel() for v in stops]))
         print(model, "f", out[f"{model}/camera"][:, 2], "gt", cams[:, 2], "k", out[f"{model}/camera"][:, 6:8].ravel(), "gt", cams[:, 6:8].ravel(),
-              "1-ulp spread", spread, flush=True)
+              "1-ulp spread", spread, "stop_at", out[f"{model}/stop_at"], "under perturbation", out[f"{model}/stop_at_set"], flush=True)
     np.savez_compressed(os.path.join(HERE, "golden_full_rd.npz"), **out)
 
 

@@ -106,9 +106,13 @@ def test_hip_matches_reference_full_size_other_models(dev, model, idx):
     ref = {k.split("/", 1)[1]: g[k] for k in g.files if k.startswith(model + "/")}
     d = result_spread(out, ref)
     assert (d < 1e-4 + 10.0 * ref["spread"]).all(), (model, d, ref["spread"])
-    # stop_at: the step at which every cost has stopped moving by 1e-8 -- these two models creep along a flat
-    # distortion valley, so the crossing is rounding noise: the same step or its neighbour
-    assert np.abs(out["stop_at"] - ref["stop_at"]).max() <= 1, (out["stop_at"], ref["stop_at"])
+    # stop_at: the step at which every cost has stopped moving by 1e-8, a threshold crossing.  Gated by what the
+    # REFERENCE's own stop_at does under 1-ulp input perturbations (`stop_at_set`: the unperturbed run + 8 perturbed ones,
+    # make_golden_full_rd.py): radial creeps along a flat distortion valley and the reference itself lands on 19 or 20;
+    # simple_divisional's crossing is sharp, the reference always reports 9 -- and so must the HIP path.
+    allowed = ref["stop_at_set"]
+    assert np.isin(out["stop_at"], allowed).all(), (out["stop_at"], ref["stop_at"], allowed)
+    print(f"stop_at {model}: HIP {out['stop_at']} reference {ref['stop_at']} reference under 1-ulp perturbations {allowed}")
     assert np.abs(out["covariance"] - ref["covariance"]).max() / np.abs(ref["covariance"]).max() < 1e-3
 
 
@@ -863,6 +867,7 @@ def test_randomised_configurations_against_oracle(dev, oracle):
     div = np.load(div_path) if n_models == 4 and os.path.exists(div_path) else None
     worst, against_reference, spent, failures, stop_shifts, excused = {}, 0, np.zeros(2), [], [], []
     undetermined = {m: 0 for m in ALL_MODELS}
+    first_step = {m: 0 for m in ALL_MODELS}     # of the undetermined draws: compared after ONE LM step instead
     drawn = {m: 0 for m in ALL_MODELS}
     for case, model, (H, W), B, data, conf, cams, gravs in fuzz_draws(seed, n_cases, n_models):
         t0 = time.perf_counter()
@@ -917,8 +922,26 @@ def test_randomised_configurations_against_oracle(dev, oracle):
             kind = ("oracle-loose" if model == "simple_divisional" else "oracle") + "@hip-stop"
         rec = {"model": model, "yardstick": kind, "own": own.tolist()}
         if own.max() > 1e-3:
+            # The END of this draw's trajectory is not a yardstick -- but its BEGINNING is: rounding noise needs steps to be
+            # amplified.  One LM step from the same start (no early stop) is compared instead, under the same rule (the
+            # oracle in float32 against itself in float64 and under two 1-ulp perturbations decides whether even that
+            # is sharp); only a draw whose FIRST step is not reproducible is left at "finite".  
             undetermined[model] += 1
-            MEASURED[f"fuzz/{seed}/{case}"] = {**rec, "undetermined": True}
+            at1 = {**conf, "num_steps": 1, "early_stop": False}
+            y1 = oracle.solve(data, at1, precision="f32")
+            own1 = result_spread(y1, oracle.solve(data, at1, precision="f64"))
+            for _ in range(2):
+                own1 = np.maximum(own1, result_spread(oracle.solve(perturbed(data, prng), at1, precision="f32"), y1))
+            rec = {**rec, "undetermined": True, "own_first_step": own1.tolist()}
+            if own1.max() <= 1e-3:
+                d1 = result_spread(run(at1, data, dev), y1)
+                tol1 = FUZZ_GATE[model] + 10.0 * own1.max()
+                first_step[model] += 1
+                rec |= {"first_step_spread": d1.tolist(), "first_step_tol": tol1.tolist()}
+                if not (d1 < tol1).all():
+                    failures.append((case, model, (H, W), B, at1, d1.tolist(), tol1.tolist(), "first LM step of an undetermined draw"))
+                    rec["FAILED"] = True
+            MEASURED[f"fuzz/{seed}/{case}"] = rec
             continue
         against_reference += kind == "reference"
         worst[case] = result_spread(out, yard)
@@ -933,6 +956,12 @@ def test_randomised_configurations_against_oracle(dev, oracle):
             (excused if why else failures).append(rec2)
             MEASURED[f"fuzz/{seed}/{case}"]["excused" if why else "FAILED"] = why or True
     w = np.array(list(worst.values()))
+    compared = {m: round(1.0 - undetermined[m] / drawn[m], 3) for m in ALL_MODELS if drawn[m]}
+    compared_any = {m: round(1.0 - (undetermined[m] - first_step[m]) / drawn[m], 3) for m in ALL_MODELS if drawn[m]}
+    MEASURED[f"fuzz_summary/{seed}"] = {"draws": drawn, "undetermined": undetermined, "undetermined_compared_at_first_step": first_step,
+                                        "fraction_compared_at_the_end": compared, "fraction_compared_at_all": compared_any}
+    print(f"fuzz seed {seed}: fraction of the draws compared with the yardstick at the END of the solve {compared}, "
+          f"at the end or (undetermined there) after the first step {compared_any}")
     print(f"fuzz seed {seed}: {n_cases} draws {drawn}, undetermined {undetermined}, {against_reference} simple_divisional "
           f"draws gated by the reference, {len(stop_shifts)} compared at the HIP path's stop step (shifts {sorted(stop_shifts)}), {len(failures)} beyond their gate, {len(excused)} beyond it on an unstable yardstick {[(e[0], e[1], e[-1]) for e in excused]}, median spread {np.median(w, axis=0)}, worst "
           f"{w.max(axis=0)}, seconds in the oracle {spent[0]:.1f} / in the HIP path {spent[1]:.1f}")
@@ -941,6 +970,10 @@ def test_randomised_configurations_against_oracle(dev, oracle):
     if seed == 2024 and n_cases == 80 and n_models == 4:
         assert undetermined == FUZZ_UNDETERMINED_2024 and not excused, (undetermined, excused)
     assert sum(undetermined.values()) <= 0.3 * n_cases, undetermined
+    for m in ALL_MODELS:          # no model's fuzz may degenerate into "finite only" (VERDICT r04 #4b); small samples: 80-draw runs
+        if drawn[m] >= 10:
+            assert compared[m] >= 0.5, (m, compared, drawn, undetermined)
+            assert compared_any[m] >= 0.8, (m, compared_any, drawn, undetermined, first_step)
     if div is not None and seed in (2024, *range(11, 23)):
         assert against_reference >= 5, against_reference      # simple_divisional really was drawn and TIGHTLY gated by the reference
     med = np.median(w, axis=0)
