@@ -97,6 +97,7 @@ _SIGNATURES = {
     "gclm_merge_stop_at": (C.c_int, [C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int), C.c_int, _P]),
     "gclm_set_sweep_iters": (C.c_int, [_P, C.c_int]),
     "gclm_set_slat_plane": (C.c_int, [_P, C.c_int]),
+    "gclm_plan_cut": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gclm_set_fused_steps": (C.c_int, [_P, C.c_int]),
     "gclm_set_paced_launches": (C.c_int, [_P, C.c_int]),
     "gclm_set_timing": (C.c_int, [_P, C.c_int]),

@@ -386,6 +386,15 @@ int gclm_set_sweep_iters(gclm_handle* h, int iters) {
     return 0;
 }
 
+int gclm_plan_cut(const gclm_handle* h, int B, int H, int W, int aligned16, int* rows_per_chunk, int* chunks_per_image) {
+    if (!h) return -1;
+    if (B < 1 || H < 1 || W < 1) return -3;
+    const Geometry geo = plan_geometry(B, H, W, aligned16 != 0, h->sweep_iters, h->cfg.camera_model);
+    if (rows_per_chunk) *rows_per_chunk = geo.rows_per_block;
+    if (chunks_per_image) *chunks_per_image = geo.nchunks;
+    return 0;
+}
+
 int gclm_set_slat_plane(gclm_handle* h, int mode) {
     if (!h) return -1;
     if (mode < -1 || mode > 1) return fail(h, -3, "gclm_set_slat_plane: mode %d not in {-1, 0, 1}", mode);
@@ -412,6 +421,9 @@ int gclm_merge_stop_at(gclm_handle* const* parts, float* const* d_info, const in
         if (!h || !h->ctx.ctrl || (B[p] > 0 && !d_info[p])) return fail(h0, -3, "gclm_merge_stop_at: part %d has not solved anything", p);
         if (h->device != h0->device || h->cfg.num_steps != h0->cfg.num_steps || h->cfg.early_stop)
             return fail(h0, -2, "gclm_merge_stop_at: the parts must share device and num_steps and run with early_stop = 0");
+        if (B[p] != h->ctx.B)       // the counters in this handle's workspace are those of its LAST solve
+            return fail(h0, -2, "gclm_merge_stop_at: part %d is given as %d images, but the last solve of its handle had %d", p, B[p],
+                        h->ctx.B);
         a.ctrl[p] = h->ctx.ctrl;
         a.info[p] = d_info[p];
         a.B[p] = B[p];

@@ -9,10 +9,12 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <new>
 #include <string>
+#include <utility>
 
 #include "../../include/gclm.h"
 
@@ -38,9 +40,11 @@ struct Rccl {
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
+    std::string why;      // !ok: the loader's message, or the entry point that is missing
 };
 Rccl g_rccl;
 std::once_flag g_rccl_once;
+std::atomic<bool> g_rccl_bound{false};
 const Rccl& rccl() {
     std::call_once(g_rccl_once, [] {
         Rccl& r = g_rccl;
@@ -48,8 +52,16 @@ const Rccl& rccl() {
         for (const char* n : names)                                    // already in the process?
             if (!r.lib && (r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) r.origin = std::string(n) + " (already loaded by the process)";
         if (!r.lib && (r.lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL))) r.origin = "/opt/rocm/lib/librccl.so.1";
-        if (!r.lib && (r.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL))) r.origin = "librccl.so.1 (loader path)";
-        if (!r.lib) return;
+        if (!r.lib) {
+            dlerror();
+            if ((r.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL))) r.origin = "librccl.so.1 (loader path)";
+            else if (const char* e = dlerror()) r.why = e;
+        }
+        g_rccl_bound.store(true);
+        if (!r.lib) {
+            r.why = "no librccl in the process, under /opt/rocm/lib or on the loader path (" + r.why + ")";
+            return;
+        }
         r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(dlsym(r.lib, "ncclGetVersion"));
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
@@ -57,7 +69,15 @@ const Rccl& rccl() {
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
         r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.lib, "ncclAllReduce"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
-        r.ok = r.GetVersion && r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.AllReduce && r.GetErrorString;
+        const std::pair<const char*, bool> need[] = {{"ncclGetVersion", r.GetVersion}, {"ncclGetUniqueId", r.GetUniqueId},
+            {"ncclCommInitRank", r.CommInitRank}, {"ncclCommDestroy", r.CommDestroy}, {"ncclAllGather", r.AllGather},
+            {"ncclAllReduce", r.AllReduce}, {"ncclGetErrorString", r.GetErrorString}};
+        r.ok = true;
+        for (const auto& n : need)
+            if (!n.second) {
+                r.ok = false;
+                r.why += (r.why.empty() ? r.origin + " lacks " : std::string(", ")) + n.first;
+            }
     });
     return g_rccl;
 }
@@ -75,16 +95,31 @@ int gclm_comm_unique_id(void* id_out) {
     if (!id_out) return cfail(nullptr, -1, "gclm_comm_unique_id", "null argument");
     static_assert(sizeof(ncclUniqueId) == GCLM_COMM_ID_BYTES, "unique id size");
     const Rccl& L = rccl();
-    if (!L.ok) return cfail(nullptr, -22, "gclm_comm_unique_id", "no usable librccl in the process or under /opt/rocm/lib");
+    if (!L.ok) return cfail(nullptr, -22, "gclm_comm_unique_id", L.why.c_str());
     ncclResult_t r = L.GetUniqueId(static_cast<ncclUniqueId*>(id_out));
     return r == ncclSuccess ? 0 : cfail(nullptr, -20, "ncclGetUniqueId", L.GetErrorString(r));
 }
 
 int gclm_comm_versions(int* compiled, int* runtime) {
-    // the rccl.h this file was compiled against and the librccl rccl() bound (see there); 0 when none could be loaded
+    // The rccl.h this file was compiled against, and the librccl the gclm_comm_* calls talk to.  This query must not be
+    // what DECIDES the latter (a caller asking for versions before torch has loaded its own librccl would pin ROCm's for
+    // the life of the process): once a gclm_comm_* call has bound one, that one is reported; before that, the librccl
+    // already loaded in the process (what a binding now would pick) is asked without being bound; 0 = none loaded yet.
     int rt = 0;
-    const Rccl& L = rccl();
-    if (!L.ok || L.GetVersion(&rt) != ncclSuccess) rt = 0;
+    if (g_rccl_bound.load()) {
+        const Rccl& L = rccl();
+        if (!L.ok || L.GetVersion(&rt) != ncclSuccess) rt = 0;
+    } else {
+        const char* names[] = {"librccl.so.1", "librccl.so"};
+        for (const char* n : names) {
+            void* lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+            if (!lib) continue;
+            auto get = reinterpret_cast<ncclResult_t (*)(int*)>(dlsym(lib, "ncclGetVersion"));
+            if (!get || get(&rt) != ncclSuccess) rt = 0;
+            dlclose(lib);
+            break;
+        }
+    }
     if (compiled) *compiled = NCCL_VERSION_CODE;
     if (runtime) *runtime = rt;
     return 0;
@@ -97,7 +132,7 @@ int gclm_comm_create(gclm_comm** out, const void* unique_id, int nranks, int ran
     // the three entry points used here (ncclCommInitRank / ncclAllGather / ncclAllReduce) are stable within a major
     // version; a librccl of another major version must not be driven through this header's declarations
     const Rccl& L = rccl();
-    if (!L.ok) return cfail(nullptr, -22, "gclm_comm_create", "no usable librccl in the process or under /opt/rocm/lib");
+    if (!L.ok) return cfail(nullptr, -22, "gclm_comm_create", L.why.c_str());
     int rt = 0;
     if (L.GetVersion(&rt) != ncclSuccess || rt / 10000 != NCCL_VERSION_CODE / 10000) {
         std::string m = "librccl at run time reports version " + std::to_string(rt) + ", this library was compiled against " +

@@ -539,10 +539,13 @@ __global__ void synth_kernel(int model, uint64_t seed, int64_t first, int B, int
             d = 1.f + t.k1 * r2 + t.k2 * r2 * r2; d1x2 = 2.f * t.k1 + 4.f * t.k2 * r2;
             e = 1.f - t.k1 * r2 + (3.f * t.k1 * t.k1 - t.k2) * r2 * r2;
         } else if (model == GCLM_SIMPLE_DIVISIONAL) {
-            const float den = 2.f * t.k1 * r2;
-            d = den == 0.f ? 1.f : (1.f - sqrtf(fmaxf(1.f - 4.f * t.k1 * r2, 0.f))) / den;
-            const float t0 = sqrtf(fmaxf(1.f - 4.f * t.k1 * r2, 1e-6f)), a1 = t0 * 2.f * r2, a2 = t.k1 * r2 * r2;
-            d1x2 = a1 * a2 == 0.f ? 0.f : (4.f * a2 - (1.f - t0) * a1) / (a1 * a2);
+            // s = (1 - t) / (2 k r2), t = sqrt(1 - 4 k r2), and its derivative cancel catastrophically in float32 for small
+            // k r2 (the reference's own forms, camera.py:829-868, flagged at :913): up to 1.6e-3 in the up vector.  The
+            // generator renders the TRUE field, so it takes the algebraically equal conjugate forms
+            // s = 2 / (1 + t), 2 ds/dr2 = 8 k / (t (1 + t)^2)  (test_synth_generator_renders_the_reference_field).
+            const float ts = sqrtf(fmaxf(1.f - 4.f * t.k1 * r2, 0.f)), t0 = sqrtf(fmaxf(1.f - 4.f * t.k1 * r2, 1e-6f));
+            d = 2.f / (1.f + ts);
+            d1x2 = 8.f * t.k1 / (t0 * (1.f + t0) * (1.f + t0));
             e = 1.f / (1.f + t.k1 * r2);
         }
         const float tt = u * px + v * py;

@@ -26,7 +26,8 @@ def default_preprocess(img: torch.Tensor, resize: int = 320, edge_divisible_by: 
     """Short side to `resize` px (antialiased bilinear), centre-crop to multiples of `edge_divisible_by`.
     Same bookkeeping keys as the reference's ImagePreprocessor (geocalib/utils.py:68-160), plus `_host`: the same numbers
     as Python floats (they only depend on the image SHAPE), which lets `_post_process` skip a device-to-host read and a
-    dozen tiny tensor kernels.  The bookkeeping tensors are cached per input shape (no host-to-device copy per call)."""
+    dozen tiny tensor kernels.  The bookkeeping numbers are cached on the device per input shape (no host-to-device copy per
+    call); every call returns its own copy of them."""
     h, w = img.shape[-2:]
     s = resize / min(h, w)
     nh, nw = int(round(h * s)), int(round(w * s))
@@ -37,12 +38,13 @@ def default_preprocess(img: torch.Tensor, resize: int = 320, edge_divisible_by: 
     key = (h, w, resize, edge_divisible_by, img.device, img.dtype)
     cached = _PRE_CACHE.get(key)
     if cached is None:
-        scales = torch.tensor([nw / w, nh / h], dtype=img.dtype, device=img.device)
-        crop_pad = torch.tensor([cw - nw, ch - nh], dtype=img.dtype, device=img.device)
         if len(_PRE_CACHE) > 64:
             _PRE_CACHE.clear()
-        cached = _PRE_CACHE[key] = (scales, crop_pad)
-    scales, crop_pad = cached
+        cached = _PRE_CACHE[key] = torch.tensor([nw / w, nh / h, cw - nw, ch - nh], dtype=img.dtype, device=img.device)
+    # the caller gets its OWN copy (one 16-byte device copy, no host-to-device transfer): an in-place edit of
+    # data["scales"] must not reach the next image of this shape
+    own = cached.clone()
+    scales, crop_pad = own[:2], own[2:]
     return {"image": out, "scales": scales, "crop_pad": crop_pad,
             "_host": {"scales": (nw / w, nh / h), "crop_pad": (float(cw - nw), float(ch - nh)), "size": (int(w), int(h))}}
 

@@ -444,7 +444,7 @@ class LMOptimizer(nn.Module):
         grav = torch.empty((B, 3), dtype=torch.float32, device=device)
         info = torch.empty((B, _lib.INFO_STRIDE), dtype=torch.float32, device=device)
         P = self._ptr           # (the library switches to the handle's device itself: no torch.cuda.device() context)
-        n_over = self._overlap_parts(B, H, W)
+        n_over = self._overlap_parts(B, H, W, h, all(t is None or t.data_ptr() % 16 == 0 for t in (up, lat, upc, latc)))
         if n_over > 1:
             self._calibrate_overlapped(n_over, device, (up, lat, upc, latc), (B, H, W), scales, (pf, pg, pd), nd, (cam, grav, info))
         else:
@@ -472,11 +472,23 @@ class LMOptimizer(nn.Module):
     _OVERLAP_MIN_IMAGES = 256
     _OVERLAP_AUTO_PIXELS = 3 * 2048 * 20480      # 3 x (2048 workgroups x 20 480 pixels per workgroup at 20 iterations)
 
-    def _overlap_parts(self, B: int, H: int = 480, W: int = 640) -> int:
+    def _overlap_parts(self, B: int, H: int = 480, W: int = 640, handle=None, aligned16: bool = True) -> int:
         if self.conf.early_stop or self.shared_intrinsics:
             return 1
         if self.overlap_streams is None:
-            return 2 if (B // 2 >= self._OVERLAP_MIN_IMAGES and (B // 2) * H * W >= self._OVERLAP_AUTO_PIXELS) else 1
+            if not (B // 2 >= self._OVERLAP_MIN_IMAGES and (B // 2) * H * W >= self._OVERLAP_AUTO_PIXELS):
+                return 1
+            if handle is None:
+                return 2
+            # the promise of the automatic mode is the single call's bits: the LIBRARY says how it would cut the whole batch
+            # and each part (gclm_plan_cut; the side-stream handles share this handle's configuration) -- no mirrored rule
+            cuts = set()
+            for n in (B, B // 2, B - B // 2):
+                rows = _lib.C.c_int(0)
+                _lib.check(_lib.load().gclm_plan_cut(handle.ptr, n, H, W, int(aligned16), _lib.C.byref(rows), None), handle.ptr,
+                           "gclm_plan_cut")
+                cuts.add(rows.value)
+            return 2 if len(cuts) == 1 else 1
         n = int(self.overlap_streams)
         if n <= 1:
             return 1

@@ -7,7 +7,11 @@
  * `GeoCalib.optimizer` (geocalib/geocalib.py:106,119), an `LMOptimizer` (geocalib/lm_optimizer.py:141).
  * Every entry point below states which reference function(s) it replaces.  All pointers named
  * `d_*` are DEVICE pointers owned by the caller (torch-ROCm tensors); `stream` is a hipStream_t
- * passed as void*.  Calls are asynchronous on `stream` and never synchronise the device.
+ * passed as void*.  Calls are asynchronous on `stream` and never synchronise the device -- with ONE exception: a
+ * handle's workspace is allocated by the first solve and GROWN by the first solve of a larger shape than any before
+ * (batch size, chunks per image, groups, the sin(latitude) scratch plane): that call runs hipFree + hipMalloc, which
+ * synchronises the device once.  Every later call of that shape or a smaller one finds the workspace in place: no
+ * allocation and no synchronisation after warm-up (gclm_workspace_bytes reports its size).
  * Return value: 0 = ok, negative = error (message via gclm_last_error).  No C++ exception crosses
  * this boundary.  A handle is not thread-safe and owns the whole solve workspace: one handle per (device, stream).
  * Every entry point runs on the handle's device and restores the caller's current HIP device before it returns.
@@ -35,7 +39,7 @@ extern "C" {
  * struct_size / abi_version / device moved into gclm_config, gclm_create lost its third argument, new entry points
  * gclm_set_sweep_iters, gclm_set_fused_steps, gclm_set_paced_launches, gclm_set_stop_comm, gclm_comm_all_reduce_sum_i32,
  * gclm_abi_config_size; 400 = round 4: gclm_comm_versions, gclm_merge_stop_at and gclm_upsample_fields_multi added, the NULL-handle error strings became thread-local, an
- * empty batch (B = 0, NULL fields) is accepted by gclm_solve / gclm_calibrate; 500 = round 5: gclm_set_slat_plane added).  gclm_create refuses a gclm_config whose first two fields do not
+ * empty batch (B = 0, NULL fields) is accepted by gclm_solve / gclm_calibrate; 500 = round 5: gclm_set_slat_plane and gclm_plan_cut added).  gclm_create refuses a gclm_config whose first two fields do not
  * carry the library's own sizeof(gclm_config) and GCLM_VERSION, with a message naming both sides. */
 #define GCLM_VERSION 500
 
@@ -299,7 +303,11 @@ const char* gclm_comm_last_error(const gclm_comm* c);
  * run time.  The library is not LINKED against librccl: on first use it takes the RCCL the process has already loaded
  * (a torch process: torch's own librccl.so, the one torch.distributed's communicators live in), otherwise
  * /opt/rocm/lib/librccl.so.1.  gclm_comm_create refuses (-21) a run-time library of another MAJOR version, and every
- * gclm_comm_* entry point fails with -22 when no librccl can be loaded at all. */
+ * gclm_comm_* entry point fails with -22 when no librccl can be loaded at all (gclm_comm_last_error(NULL) then carries the
+ * loader's message or the name of the missing entry point).  The choice is made by the first gclm_comm_unique_id /
+ * gclm_comm_create of the process and holds for its lifetime: a process that also uses torch.distributed MUST import
+ * torch before that call.  gclm_comm_versions itself never makes the choice: before one was made it reports the version
+ * of the librccl already loaded in the process (what a binding now would pick), or runtime = 0 when none is loaded yet. */
 int gclm_comm_versions(int* compiled, int* runtime);
 int gclm_comm_all_gather(gclm_comm* c, const float* d_send, float* d_recv, size_t count_per_rank, void* stream);
 int gclm_comm_all_reduce_sum(gclm_comm* c, float* d_buf, size_t count, void* stream);
@@ -318,15 +326,25 @@ int gclm_set_stop_comm(gclm_handle* h, gclm_comm* c);
 /* A batch of independent images solved as several PARTS by several handles (e.g. on several streams of one device, so
  * that one part's update launches run under another part's sweep; early_stop = 0): every output of a part is what the
  * single call would have produced for those images, except infos["stop_at"] -- the reference's "first step after which
- * EVERY image's cost was close" (lm_optimizer.py:619-620) is one number for the whole batch.  Call this after all parts
- * have finished (stream order is the caller's business): it re-derives stop_at from the SUM of the parts' per-step
- * counters and writes it into every row of every part's info.  At most 8 parts, same device / num_steps. */
+ * EVERY image's cost was close" (lm_optimizer.py:619-620) is one number for the whole batch.  It re-derives stop_at from
+ * the SUM of the parts' per-step counters and writes it into every row of every part's info.  At most 8 parts, same
+ * device / num_steps.  The counters live in each handle's workspace and are those of the handle's LAST solve, so:
+ *   - B[p] MUST be the batch size of part p's last gclm_solve / gclm_calibrate (checked: -2 otherwise);
+ *   - `stream` MUST be ordered after every part's solve (events / stream waits are the caller's business), and no part
+ *     handle may start another solve before the merge kernel has run (it would overwrite the counters being summed). */
 int gclm_merge_stop_at(gclm_handle* const* parts, float* const* d_info, const int* B, int n_parts, void* stream);
 
 /* Tuning / test hook (no reference counterpart): loop iterations per workgroup of the sweep (how an image is cut
  * into partial records; only the summation order depends on it).  0 restores the built-in choice (20, fewer for
  * small batches).  Replaces the GCLM_SWEEP_ITERS environment variable of rounds 1-2: the solve reads no environment. */
 int gclm_set_sweep_iters(gclm_handle* h, int iters);
+/* How this handle's next solve of B images of (H, W) would cut an image into workgroup chunks: rows per chunk and
+ * chunks per image (`aligned16`: all field pointers 16-byte aligned).  The cut fixes the summation order of an image's
+ * partial records, so two calls agree bit for bit on an image exactly when their cuts agree; a caller that solves ONE
+ * batch in several parts (gclm_merge_stop_at; LMOptimizer.overlap_streams) asks here instead of mirroring the rule.  The
+ * cut depends on the batch size only below 2048 chunks per call (small batches take fewer rows per chunk to fill the
+ * GPU).  Either output pointer may be NULL.  No device work. */
+int gclm_plan_cut(const gclm_handle* h, int B, int H, int W, int aligned16, int* rows_per_chunk, int* chunks_per_image);
 
 /* sin(latitude_field) (lm_optimizer.py:262,270) does not depend on the parameters, yet each of the num_steps + 1 sweeps of
  * a solve would re-evaluate it per pixel.  For the VALU-bound distortion models the first sweep of a solve therefore

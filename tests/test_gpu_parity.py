@@ -416,6 +416,52 @@ def test_synth_generator_is_index_keyed(dev):
     assert torch.equal(cg[sel], c1) and torch.equal(gg[sel], g1)
 
 
+@pytest.mark.parametrize("model", ALL_MODELS)
+def test_synth_generator_renders_the_reference_field(dev, oracle, model):
+    """The device generator behind bench.py's inputs (synth_kernel) at the FIELD level: with noise = 0 its up /
+    latitude planes are the perspective field of its own ground truth as `oracle.render` evaluates it in float64
+    (tests/test_oracle.py pins that to the reference's get_perspective_field, perspective_fields.py:278); with the bench's
+    noise the deviation from that field is N(0, sigma) per component (latitude directly; up: the tangential part, the
+    field is re-normalised), sigma = 0.02 +- 2 %, and the confidences are U(0, 1)."""
+    from conftest import MEASURED
+    B, H, W = 3, 96, 128
+    clean, cam, grav = synth_device(model, B, H, W, dev, seed=5, noise=0.0)
+    up_ref, lat_ref = oracle.render(model, H, W, cam.cpu().numpy(), grav.cpu().numpy(), precision="f64")
+    assert np.array_equal(cam[:, :2].cpu().numpy(), np.tile(np.float32([W, H]), (B, 1)))
+    up, lat = clean["up_field"].cpu().numpy(), clean["latitude_field"].cpu().numpy()
+    lim = np.pi / 2 - 1e-3                                    # the generator clamps the latitude there (as oracle/synth.py)
+    inside = np.abs(lat_ref) < lim - 1e-4
+    assert inside.mean() > 0.99
+    # latitude = asin(s): towards the poles one float32 ulp of s is 1 / cos(latitude) ulps of the latitude (x900 at the
+    # generator's clamp), so the latitude itself is held to 2e-6 below 1.3 rad and its SINE -- what the residual uses
+    # (lm_optimizer.py:262,270) -- everywhere
+    mid = inside & (np.abs(lat_ref) < 1.3)
+    d_up, d_lat, d_sin = np.abs(up - up_ref).max(), np.abs(lat - lat_ref)[mid].max(), np.abs(np.sin(lat.astype(np.float64)) - np.sin(lat_ref.astype(np.float64)))[inside].max()
+    MEASURED[f"synth_field/{model}"] = {"up": float(d_up), "latitude_below_1.3rad": float(d_lat), "sin_latitude": float(d_sin),
+                                        "share_below_1.3rad": float(mid.mean())}
+    assert d_up <= 2e-6 and d_lat <= 2e-6 and d_sin <= 2e-6, (model, d_up, d_lat, d_sin)
+    sigma = 0.02
+    noisy, cam_n, grav_n = synth_device(model, B, H, W, dev, seed=5, noise=sigma)
+    assert torch.equal(cam_n, cam) and torch.equal(grav_n, grav)
+    un, ln = noisy["up_field"].cpu().numpy().astype(np.float64), noisy["latitude_field"].cpu().numpy().astype(np.float64)
+    assert np.abs(np.sqrt((un ** 2).sum(1)) - 1).max() < 1e-6
+    tangential = up_ref[:, 0] * un[:, 1] - up_ref[:, 1] * un[:, 0]          # sin(angle between the noisy and the clean up vector)
+    unclamped = inside & (np.abs(ln) < lim - 1e-6)
+    dl = (ln - lat_ref)[unclamped]
+    n = tangential.size
+    stats = {"up_tangential_std": float(tangential.std()), "up_tangential_mean": float(tangential.mean()),
+             "latitude_std": float(dl.std()), "latitude_mean": float(dl.mean())}
+    MEASURED[f"synth_noise/{model}"] = stats
+    for key in ("up_tangential", "latitude"):
+        assert abs(stats[key + "_std"] / sigma - 1) < 0.02, stats
+        assert abs(stats[key + "_mean"]) < 5 * sigma / np.sqrt(n), stats
+    for key in ("up_confidence", "latitude_confidence"):
+        c = noisy[key].cpu().numpy().astype(np.float64)
+        assert 0 < c.min() and c.max() < 1 and abs(c.mean() - 0.5) < 5 / np.sqrt(12 * n) and abs(c.var() * 12 - 1) < 0.03, key
+    # independent draws per plane and pixel: no correlation between the two noise components
+    assert abs(np.corrcoef(tangential[unclamped[:, 0]], dl)[0, 1]) < 5 / np.sqrt(dl.size)
+
+
 @pytest.mark.parametrize("model", HIP_MODELS)
 def test_full_size_batch_properties(dev, oracle, model):
     """BASELINE configs[1]/[3]: B=1024, 640x480, 20 iterations.  Size-independent properties:
@@ -742,6 +788,28 @@ def test_sharded_early_stop_through_the_stop_communicator(dev):
         early = lo if lo["stop_at"][0] < hi["stop_at"][0] else hi
         sl = slice(0, 6) if early is lo else slice(6, 12)
         assert not np.array_equal(early["camera"], whole["camera"][sl])           # per-shard decisions change the answer
+
+
+@pytest.mark.parametrize("model", HIP_MODELS)
+def test_sharded_early_stop_at_the_baseline_size_through_rccl(dev, model):
+    """VERDICT r04 #6a: `calibrate_sharded(early_stop=True)` at B = 1024, 640x480 with the stop counters travelling through
+    gclm_set_stop_comm, on the direct RCCL route AND on the torch ("nccl") route, one rank: `stop_at` and every result bit
+    equal the plain call's (tests/rccl_stop_probe.py, its own process: it initialises a process group)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import MEASURED, ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("NCCL_DEBUG", None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_stop_probe.py"), model, "1024", str(29700 + os.getpid() % 200)],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    MEASURED[f"rccl_stop/{model}"] = out
+    st = out["stop_at"]
+    assert st["plain"] == st["gclm_comm"] == st["torch_nccl"] and 1 < st["plain"] < 30, st
+    assert out["identical_to_plain"] == {"gclm_comm": True, "torch_nccl": True}, out
+    assert out["torch_route_made_a_stop_communicator"] and out["rccl"]["runtime"] // 10000 == 2, out
 
 
 def test_rccl_c_abi_single_rank(dev):
@@ -1940,3 +2008,33 @@ def test_overlap_streams_equals_the_single_call(dev, model):
     assert auto._overlap_parts(1024, 480, 640) == 2 and auto._overlap_parts(820, 480, 640) == 2
     assert auto._overlap_parts(513, 480, 640) == 1 and auto._overlap_parts(4096, 96, 128) == 1
     assert LMOptimizer({"camera_model": model})._overlap_parts(1024, 480, 640) == 1            # early stop
+    # ... and asks the LIBRARY whether the parts are cut like the batch (gclm_plan_cut), instead of mirroring its rule
+    from geocalib_amd import _lib
+    lib, C = _lib.load(), _lib.C
+    h = auto._handle(dev)
+
+    def cut(n, hh=480, ww=640):
+        rows, chunks = C.c_int(0), C.c_int(0)
+        assert lib.gclm_plan_cut(h.ptr, n, hh, ww, 1, C.byref(rows), C.byref(chunks)) == 0
+        return rows.value, chunks.value
+    # 640x480: two rows per loop iteration, 20 (pinhole) / 30 iterations per chunk; below 2048 chunks per call the
+    # library takes fewer rows per chunk -- where that regime ends depends on the camera model (pinhole: 137 images of 15
+    # chunks, the others: 205 of 10), which is why the Python side no longer mirrors the rule
+    assert cut(1024) == cut(512) == cut(256) and cut(1)[0] < cut(1024)[0]
+    assert cut(1024) == ((40, 15) if model == "pinhole" else (60, 10))
+    assert (cut(137) == cut(1024)) == (model == "pinhole") and cut(205) == cut(1024)
+    assert auto._overlap_parts(1024, 480, 640, h, True) == 2
+    assert lib.gclm_set_sweep_iters(h.ptr, 7) == 0 and cut(1024)[0] == 14 and lib.gclm_set_sweep_iters(h.ptr, 0) == 0
+    assert lib.gclm_plan_cut(h.ptr, 0, 480, 640, 1, None, None) == -3 and lib.gclm_plan_cut(None, 1, 480, 640, 1, None, None) == -1
+    # gclm_merge_stop_at refuses a part whose handle last solved another batch size (its counters are not that part's)
+    hs = list(opt2._handles.values())[-2:]
+    info = torch.zeros((B, _lib.INFO_STRIDE), device=dev)
+    parts = (C.c_void_p * 2)(*[x.ptr.value for x in hs])
+    infos = (C.c_void_p * 2)(info[:256].data_ptr(), info[256:].data_ptr())
+    good = (C.c_int * 2)(*[B * 1 // 2, B - B // 2])
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    torch.cuda.synchronize()
+    assert lib.gclm_merge_stop_at(parts, infos, good, 2, stream) == 0, _lib.last_error(hs[0].ptr)
+    bad = (C.c_int * 2)(B // 2, B - B // 2 - 1)
+    assert lib.gclm_merge_stop_at(parts, infos, bad, 2, stream) == -2 and "last solve" in _lib.last_error(hs[0].ptr)
+    torch.cuda.synchronize()
