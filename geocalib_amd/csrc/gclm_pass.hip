@@ -98,6 +98,9 @@
                                     // built-in choice does not use them (memory-bound: the plane's one extra write costs
                                     // what the saved VALU work gains), gclm_set_slat_plane(h, 1) does (measurement)
 #endif
+#ifndef GCLM_DIV_SQRT_REFINE
+#define GCLM_DIV_SQRT_REFINE 1      // A/B switch: 0 = simple_divisional takes v_sqrt_f32 as it comes (rounds 2-4)
+#endif
 #ifndef GCLM_DIV_GUARD_ALWAYS
 #define GCLM_DIV_GUARD_ALWAYS 0     // A/B switch: 1 = simple_divisional always runs the guarded body (round-2 behaviour)
 #endif
@@ -319,9 +322,20 @@ __device__ __forceinline__ void radial_terms(const PBlock& P, F r2, Radial<F>& R
         const F tt = vfma(r2, vsplat(r2, -4.0f * k), one);           // 1 - 4 k r2
         const F rk = r2 * k;
         const F tiny = vsplat(r2, 1e-6f);
-        const F ssq = vsqrt_hw(vmax(tt, zero));
         const F t0 = vmax(tt, tiny);
+#if GCLM_DIV_SQRT_REFINE
+        // 1 - sqrt(1 - 4 k r2) cancels: one ulp of the root is 1 / (2 |k| r2) ulps of the difference, and v_sqrt_f32's
+        // ulp is not a zero-mean rounding like the correctly rounded root the reference takes (torch.sqrt) -- at
+        // |k| = 1e-3 the FINAL COST of an image came out 2e-4 off at parameters equal to 1e-7 (fuzz 15/0 after one LM
+        // step; the oracle's float32 build: 3e-6).  One Newton step on the exact fma residual brings the hardware root
+        // to the correctly rounded one's accuracy (its error is again zero-mean) for three packed operations.
+        const F t1h = vsqrt_hw(t0), it1 = vrcp_hw(t1h), it0 = it1 * it1;
+        const F t1 = vfma(vfma(-t1h, t1h, t0), 0.5f * it1, t1h);
+        const F ssq = vsel_eq0(t0 - tt, t1, vsqrt_hw(vmax(tt, zero)));      // tt < 1e-6 (|4 k r2| ~ 1): nothing cancels there
+#else
+        const F ssq = vsqrt_hw(vmax(tt, zero));
         const F t1 = vsqrt_hw(t0), it1 = vrcp_hw(t1), it0 = it1 * it1;
+#endif
         const F ir2 = vrcp_hw(r2), ir4 = ir2 * ir2, ir6 = ir4 * ir2;    // inf for r2 = 0: only read behind the selects
         const F omt = one - t1;
         const F r4 = r2 * r2;

@@ -36,7 +36,9 @@ for B, H, W in ((256, 480, 640), (1024, 480, 640), (1, 480, 640)):
     rows.append({"kernel": "eager torch epilogue (8 kernels)", "B": B, "H": H, "W": W, "ms": round(ms_e, 4)})
     print(rows[-1], flush=True)
     del up_raw, lat_raw, ulc, llc
-for B, (h, w), (H, W) in ((256, (240, 320), (480, 640)), (64, (320, 480), (1080, 1620)), (1, (320, 480), (1080, 1620))):
+# x2 (rows of whole lines), x3.375 (ragged rows: phase-rotated stores), one image, x1.25 (no 4-float window: per-lane gathers)
+for B, (h, w), (H, W) in ((256, (240, 320), (480, 640)), (64, (320, 480), (1080, 1620)), (1, (320, 480), (1080, 1620)),
+                          (1, (240, 320), (480, 640)), (128, (320, 448), (400, 560))):
     src = torch.randn((B, 5, h, w), device=dev)
     ms = timeit(lambda: upsample_fields(src, (H, W)))
     byt = B * 5 * 4 * (h * w + H * W)

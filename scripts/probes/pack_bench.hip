@@ -1,0 +1,102 @@
+// GPU box: stand-alone A/B of load / store cache policies for the CNN-head epilogue kernel (gclm_pack_fields):
+// five fp32 planes read and written IN PLACE (normalise / tanh-asin / sigmoid).  Same arithmetic as csrc/gclm_update.hip.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 scripts/probes/pack_bench.hip -o scripts/probes/_build/pack_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+typedef float v4 __attribute__((ext_vector_type(4)));
+
+template <bool NT> __device__ __forceinline__ v4 ld(const float* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const v4*>(p));
+    else return *reinterpret_cast<const v4*>(p);
+}
+template <bool NT> __device__ __forceinline__ void st(float* p, v4 v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<v4*>(p));
+    else *reinterpret_cast<v4*>(p) = v;
+}
+// MATH 0: copy; 1: the epilogue.  UNR: float4 units per thread and iteration
+template <bool NTL, bool NTS, int MATH, int UNR>
+__global__ __launch_bounds__(256) void k_pack(float* up, float* upc, float* lat, float* latc, int B, size_t N) {
+    const size_t units = N / 4;
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {
+        float* ox = up + (size_t)b * 2 * N;
+        float* oy = ox + N;
+        float* ol = lat + (size_t)b * N;
+        float* c1p = upc + (size_t)b * N;
+        float* c2p = latc + (size_t)b * N;
+        for (size_t i0 = ((size_t)blockIdx.x * blockDim.x) * UNR + threadIdx.x; i0 < units; i0 += (size_t)gridDim.x * blockDim.x * UNR) {
+            v4 a[UNR], bq[UNR], l[UNR], c1[UNR], c2[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const size_t i = i0 + (size_t)u * 256;
+                if (i < units) { a[u] = ld<NTL>(ox + 4 * i); bq[u] = ld<NTL>(oy + 4 * i); l[u] = ld<NTL>(ol + 4 * i); c1[u] = ld<NTL>(c1p + 4 * i); c2[u] = ld<NTL>(c2p + 4 * i); }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const size_t i = i0 + (size_t)u * 256;
+                if (i >= units) continue;
+                if (MATH) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float n = fmaxf(sqrtf(a[u][k] * a[u][k] + bq[u][k] * bq[u][k]), 1e-12f);
+                        a[u][k] /= n; bq[u][k] /= n;
+                        l[u][k] = asinf(fminf(fmaxf(tanhf(l[u][k]), -1.0f + 1e-5f), 1.0f - 1e-5f));
+                        c1[u][k] = 1.0f / (1.0f + expf(-c1[u][k]));
+                        c2[u][k] = 1.0f / (1.0f + expf(-c2[u][k]));
+                    }
+                }
+                st<NTS>(ox + 4 * i, a[u]); st<NTS>(oy + 4 * i, bq[u]); st<NTS>(ol + 4 * i, l[u]); st<NTS>(c1p + 4 * i, c1[u]); st<NTS>(c2p + 4 * i, c2[u]);
+            }
+        }
+    }
+}
+struct V { const char* name; void (*k)(float*, float*, float*, float*, int, size_t); int unr; int bx; };
+int main() {
+    const int H = 480, W = 640;
+    const size_t N = (size_t)H * W;
+    hipStream_t s; CK(hipStreamCreate(&s));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const V vs[] = {
+        {"r04 (plain ld / st), grid 128", k_pack<false, false, 1, 1>, 1, 128},
+        {"nt loads", k_pack<true, false, 1, 1>, 1, 128},
+        {"nt loads + nt stores", k_pack<true, true, 1, 1>, 1, 128},
+        {"nt stores", k_pack<false, true, 1, 1>, 1, 128},
+        {"copy, plain", k_pack<false, false, 0, 1>, 1, 128},
+        {"copy, nt both", k_pack<true, true, 0, 1>, 1, 128},
+        {"nt both, 2 units / thread", k_pack<true, true, 1, 2>, 2, 64},
+        {"nt both, grid 300 (one pass)", k_pack<true, true, 1, 1>, 1, 300},
+        {"nt both, grid 32", k_pack<true, true, 1, 1>, 1, 32},
+        {"plain, grid 300 (one pass)", k_pack<false, false, 1, 1>, 1, 300},
+    };
+    for (int B : {256, 1024}) {
+        float *up, *upc, *lat, *latc;
+        CK(hipMalloc(&up, (size_t)B * 2 * N * 4)); CK(hipMalloc(&upc, (size_t)B * N * 4)); CK(hipMalloc(&lat, (size_t)B * N * 4)); CK(hipMalloc(&latc, (size_t)B * N * 4));
+        std::vector<float> h(N * 2);
+        unsigned x = 1u;
+        for (auto& f : h) { x = x * 1664525u + 1013904223u; f = (float)(x >> 8) * (2.f / 16777216.f) - 1.f; }
+        const double bytes = (double)B * N * 4 * 10;
+        printf("== B = %d, 480x640, %.1f MB read + written in place\n", B, bytes / 1e6);
+        for (const V& v : vs) {
+            // fresh values each variant (the epilogue is not idempotent but stays finite; timing does not depend on the values)
+            for (int b = 0; b < B; ++b) CK(hipMemcpyAsync(up + (size_t)b * 2 * N, h.data(), N * 2 * 4, hipMemcpyHostToDevice, s));
+            CK(hipMemsetAsync(upc, 0, (size_t)B * N * 4, s)); CK(hipMemsetAsync(lat, 0, (size_t)B * N * 4, s)); CK(hipMemsetAsync(latc, 0, (size_t)B * N * 4, s));
+            const dim3 grid(v.bx, B < 4096 ? B : 4096);
+            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(v.k, grid, dim3(256), 0, s, up, upc, lat, latc, B, N);
+            CK(hipStreamSynchronize(s));
+            float best = 1e30f, sum = 0;
+            for (int rep = 0; rep < 3; ++rep) {
+                CK(hipEventRecord(e0, s));
+                for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(v.k, grid, dim3(256), 0, s, up, upc, lat, latc, B, N);
+                CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10; sum += ms; if (ms < best) best = ms;
+            }
+            CK(hipGetLastError());
+            printf("  %-32s mean %8.1f us  best %8.1f us = %5.2f TB/s (%.3f of 8)\n", v.name, sum / 3 * 1e3, best * 1e3, bytes / (sum / 3 * 1e-3) / 1e12, bytes / (sum / 3 * 1e-3) / 8e12);
+            fflush(stdout);
+        }
+        CK(hipFree(up)); CK(hipFree(upc)); CK(hipFree(lat)); CK(hipFree(latc));
+    }
+    return 0;
+}
