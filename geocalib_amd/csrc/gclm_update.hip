@@ -2,6 +2,8 @@
 // partials, lambda rule, damped Cholesky, manifold update, parameter blocks, uncertainty, and the
 // synthetic-field generator used for measurement.  All tiny (O(B) threads); the reference does the
 // same work with a device->host->device round trip per step (lm_optimizer.py:128-137).
+#include <type_traits>
+
 #include "gclm_device.h"
 
 namespace gclm {
@@ -591,13 +593,16 @@ __global__ void pack_fields_kernel(const float* __restrict__ up_raw, const float
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < units; i += (size_t)gridDim.x * blockDim.x) {
             float vx[VEC], vy[VEC], vl[VEC], c1[VEC], c2[VEC];
             if constexpr (VEC == 4) {
-                const float4 a = reinterpret_cast<const float4*>(ux)[i], bq = reinterpret_cast<const float4*>(uy)[i];
-                const float4 l = reinterpret_cast<const float4*>(lat_raw + (size_t)b * N)[i];
+                // every byte is read once and written once: non-temporal both ways (+4 ... 8 % over plain float4 accesses,
+                // profiles/r05_pack_bench.log)
+                typedef float pk4 __attribute__((ext_vector_type(4)));
+                auto ld4 = [](const float* p, size_t j) { return __builtin_nontemporal_load(reinterpret_cast<const pk4*>(p) + j); };
+                const pk4 a = ld4(ux, i), bq = ld4(uy, i), l = ld4(lat_raw + (size_t)b * N, i);
                 vx[0] = a.x; vx[1] = a.y; vx[2] = a.z; vx[3] = a.w;
                 vy[0] = bq.x; vy[1] = bq.y; vy[2] = bq.z; vy[3] = bq.w;
                 vl[0] = l.x; vl[1] = l.y; vl[2] = l.z; vl[3] = l.w;
-                if (up_lc) { const float4 t = reinterpret_cast<const float4*>(up_lc + (size_t)b * N)[i]; c1[0] = t.x; c1[1] = t.y; c1[2] = t.z; c1[3] = t.w; }
-                if (lat_lc) { const float4 t = reinterpret_cast<const float4*>(lat_lc + (size_t)b * N)[i]; c2[0] = t.x; c2[1] = t.y; c2[2] = t.z; c2[3] = t.w; }
+                if (up_lc) { const pk4 t = ld4(up_lc + (size_t)b * N, i); c1[0] = t.x; c1[1] = t.y; c1[2] = t.z; c1[3] = t.w; }
+                if (lat_lc) { const pk4 t = ld4(lat_lc + (size_t)b * N, i); c2[0] = t.x; c2[1] = t.y; c2[2] = t.z; c2[3] = t.w; }
             } else {
                 vx[0] = ux[i]; vy[0] = uy[i]; vl[0] = lat_raw[(size_t)b * N + i];
                 if (up_lc) c1[0] = up_lc[(size_t)b * N + i];
@@ -612,11 +617,13 @@ __global__ void pack_fields_kernel(const float* __restrict__ up_raw, const float
                 if (lat_lc) c2[k] = 1.0f / (1.0f + expf(-c2[k]));
             }
             if constexpr (VEC == 4) {
-                reinterpret_cast<float4*>(ox)[i] = make_float4(vx[0], vx[1], vx[2], vx[3]);
-                reinterpret_cast<float4*>(oy)[i] = make_float4(vy[0], vy[1], vy[2], vy[3]);
-                reinterpret_cast<float4*>(lat + (size_t)b * N)[i] = make_float4(vl[0], vl[1], vl[2], vl[3]);
-                if (up_lc) reinterpret_cast<float4*>(upc + (size_t)b * N)[i] = make_float4(c1[0], c1[1], c1[2], c1[3]);
-                if (lat_lc) reinterpret_cast<float4*>(latc + (size_t)b * N)[i] = make_float4(c2[0], c2[1], c2[2], c2[3]);
+                typedef float pk4 __attribute__((ext_vector_type(4)));
+                auto st4 = [](float* p, size_t j, const float (&v)[VEC]) {
+                    __builtin_nontemporal_store(pk4{v[0], v[1], v[2], v[3]}, reinterpret_cast<pk4*>(p) + j);
+                };
+                st4(ox, i, vx); st4(oy, i, vy); st4(lat + (size_t)b * N, i, vl);
+                if (up_lc) st4(upc + (size_t)b * N, i, c1);
+                if (lat_lc) st4(latc + (size_t)b * N, i, c2);
             } else {
                 ox[i] = vx[0]; oy[i] = vy[0]; lat[(size_t)b * N + i] = vl[0];
                 if (up_lc) upc[(size_t)b * N + i] = c1[0];
@@ -672,7 +679,7 @@ __device__ __forceinline__ void upsample_plane(const float* __restrict__ s, floa
 //     line: every full wave store then starts on a line.  Rows of 1620 floats (6480 B) are not whole lines; round 4
 //     wrote each wave's 1 KiB across nine lines, two of them partial, and the stores alone took 1.75x a flat fill
 //     (profiles/r05_upsample_bench.log: 652 -> 439 us for 64 x 5 planes 320x480 -> 1080x1620).
-//   * CONSEC (rows are whole lines, Wu % 8 == 0): a wave walks ROWS consecutive output rows; every source row it needs is
+//   * CONSEC (rows are whole 64-byte half lines, Wu % 4 == 0): a wave walks ROWS consecutive output rows; every source row it needs is
 //     loaded up front (PREF, when the vertical ratio bounds their number) and its horizontally interpolated values stay in
 //     registers for all output rows that tap it.
 //   * PHASED (ragged rows): rows 8 apart share the phase o (8 Wu = 0 mod 8 units), so wave i of a 512-thread block owns
@@ -681,13 +688,28 @@ __device__ __forceinline__ void upsample_plane(const float* __restrict__ s, floa
 typedef float up_v2 __attribute__((ext_vector_type(2)));
 typedef float up_v4 __attribute__((ext_vector_type(4)));
 typedef float up_v4u __attribute__((ext_vector_type(4), aligned(4)));
+// NW = 4: upsampling by >= 1.5 (above).  NW = 5: upsampling by 1 ... 1.5 -- four adjacent outputs then tap at most FIVE
+// consecutive source floats (one 16-byte + one 4-byte load per source row and lane, a 6-term chain); GeoCalib resizes
+// the short side to 320 px, so every input between 320 and 480 px on its short side lands here.
+template <int NW>
 struct UpCol {
-    int xs, u;              // window start (source floats), output unit of this lane
-    up_v2 W[4][2], E[2];    // weight of window float j for the outputs (0, 1) and (2, 3)
+    int xs, u;               // window start (source floats), output unit of this lane
+    up_v2 W[NW][2], E[2];    // weight of window float j for the outputs (0, 1) and (2, 3)
     bool live;
 };
-__device__ __forceinline__ UpCol up_col_weights(int q, int o, int w, int W, float sx) {
-    UpCol c;
+template <int NW>
+struct UpWin { float t[NW]; };
+template <int NW>
+__device__ __forceinline__ UpWin<NW> up_load_window(const float* p) {
+    UpWin<NW> r;
+    const up_v4u q = *reinterpret_cast<const up_v4u*>(p);
+    r.t[0] = q.x; r.t[1] = q.y; r.t[2] = q.z; r.t[3] = q.w;
+    if constexpr (NW == 5) r.t[4] = p[4];
+    return r;
+}
+template <int NW>
+__device__ __forceinline__ UpCol<NW> up_col_weights(int q, int o, int w, int W, float sx) {
+    UpCol<NW> c;
     const int Wu = W >> 2;
     int u = q + (Wu >= 64 ? o : 0);      // rows shorter than one wave store: nothing to align
     if (u >= Wu) u -= Wu;
@@ -703,28 +725,29 @@ __device__ __forceinline__ UpCol up_col_weights(int q, int o, int w, int W, floa
         x1[k] = min(x0[k] + 1, w - 1);
         lx[k] = fx - (float)x0[k];
     }
-    c.xs = min(x0[0], w - 4);
-    float Wm[4][4], Em[4];
+    c.xs = min(x0[0], w - NW);
+    float Wm[NW][4], Em[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int i0 = x0[k] - c.xs, i1 = x1[k] - c.xs;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) Wm[j][k] = (j == i1) ? lx[k] : ((j == i0) ? 1.f - lx[k] : 0.f);
+        for (int j = 0; j < NW; ++j) Wm[j][k] = (j == i1) ? lx[k] : ((j == i0) ? 1.f - lx[k] : 0.f);
         Em[k] = (i0 == i1) ? 1.f - lx[k] : 0.f;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { c.W[j][0] = up_v2{Wm[j][0], Wm[j][1]}; c.W[j][1] = up_v2{Wm[j][2], Wm[j][3]}; }
+    for (int j = 0; j < NW; ++j) { c.W[j][0] = up_v2{Wm[j][0], Wm[j][1]}; c.W[j][1] = up_v2{Wm[j][2], Wm[j][3]}; }
     c.E[0] = up_v2{Em[0], Em[1]}; c.E[1] = up_v2{Em[2], Em[3]};
     return c;
 }
-__device__ __forceinline__ void up_hwindow(const UpCol& c, const up_v4u& t, up_v2 (&o)[2]) {
+template <int NW>
+__device__ __forceinline__ void up_hwindow(const UpCol<NW>& c, const UpWin<NW>& t, up_v2 (&o)[2]) {
 #pragma unroll
     for (int hlf = 0; hlf < 2; ++hlf) {
-        up_v2 a = up_v2{t.w, t.w} * c.W[3][hlf];
-        a = __builtin_elementwise_fma(up_v2{t.w, t.w}, c.E[hlf], a);
-        a = __builtin_elementwise_fma(up_v2{t.z, t.z}, c.W[2][hlf], a);
-        a = __builtin_elementwise_fma(up_v2{t.y, t.y}, c.W[1][hlf], a);
-        a = __builtin_elementwise_fma(up_v2{t.x, t.x}, c.W[0][hlf], a);
+        const float last = t.t[NW - 1];
+        up_v2 a = up_v2{last, last} * c.W[NW - 1][hlf];
+        a = __builtin_elementwise_fma(up_v2{last, last}, c.E[hlf], a);
+#pragma unroll
+        for (int j = NW - 2; j >= 0; --j) a = __builtin_elementwise_fma(up_v2{t.t[j], t.t[j]}, c.W[j][hlf], a);
         o[hlf] = a;
     }
 }
@@ -745,28 +768,29 @@ __device__ __forceinline__ void up_vblend_store(float* p, bool live, float ly, c
 }
 __device__ __forceinline__ unsigned up_line_unit(const float* d) { return (unsigned)((reinterpret_cast<uintptr_t>(d) >> 4) & 7u); }
 
-template <int ROWS, bool PREF>
+// RMAX > 0: the rows Y0 .. Y0 + ROWS - 1 tap at most RMAX source rows (the host derives it from the vertical ratio),
+// all loaded before the arithmetic; RMAX = 0: loaded as the walk reaches them (vertical downsampling).
+template <int ROWS, int NW, int RMAX>
 __device__ __forceinline__ void upsample_consec(const float* __restrict__ s, float* __restrict__ d, int h, int w, int H, int W, int q,
                                                 int Y0) {
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
-    const UpCol c = up_col_weights(q, (int)((8u - up_line_unit(d)) & 7u), w, W, sx);
+    const UpCol<NW> c = up_col_weights<NW>(q, (int)((8u - up_line_unit(d)) & 7u), w, W, sx);
     const int Yend = min(Y0 + ROWS, H);
     const float* sc = s + c.xs;
     float* dc = d + c.u * 4;
-    if constexpr (PREF) {      // 3 h <= 2 H: rows Y0 .. Y0 + ROWS - 1 tap at most 2 ROWS / 3 + 3 source rows
-        constexpr int RMAX = 2 * ROWS / 3 + 3;
+    if constexpr (RMAX > 0) {
         const UpRow ra = up_row_terms(Y0, h, sy), rb = up_row_terms(Yend - 1, h, sy);
         const int ylo = ra.y0, yhi = rb.y1, n = yhi - ylo + 1;
-        up_v4u t[RMAX];
+        UpWin<NW> t[RMAX];
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) t[r] = *reinterpret_cast<const up_v4u*>(sc + (size_t)min(ylo + r, yhi) * w);
+        for (int r = 0; r < RMAX; ++r) t[r] = up_load_window<NW>(sc + (size_t)min(ylo + r, yhi) * w);
         up_v2 hc[2], hn[2];
-        up_hwindow(c, t[0], hc);
+        up_hwindow<NW>(c, t[0], hc);
         int Y = Y0;
 #pragma unroll
         for (int r = 0; r < RMAX; ++r) {
             if (r < n) {
-                if (r + 1 < RMAX && r + 1 < n) up_hwindow(c, t[r + 1 < RMAX ? r + 1 : r], hn);
+                if (r + 1 < RMAX && r + 1 < n) up_hwindow<NW>(c, t[r + 1 < RMAX ? r + 1 : r], hn);
                 else { hn[0] = hc[0]; hn[1] = hc[1]; }        // y1 == y0: the last source row
                 while (Y < Yend) {
                     const UpRow rt = up_row_terms(Y, h, sy);
@@ -784,37 +808,37 @@ __device__ __forceinline__ void upsample_consec(const float* __restrict__ s, flo
             const UpRow rt = up_row_terms(Y, h, sy);
             if (!(rt.y0 == ya && rt.y1 == yb)) {
                 if (rt.y0 == yb) { ha[0] = hb[0]; ha[1] = hb[1]; }
-                else if (rt.y0 != ya) up_hwindow(c, *reinterpret_cast<const up_v4u*>(sc + (size_t)rt.y0 * w), ha);
+                else if (rt.y0 != ya) up_hwindow<NW>(c, up_load_window<NW>(sc + (size_t)rt.y0 * w), ha);
                 ya = rt.y0;
                 if (rt.y1 == rt.y0) { hb[0] = ha[0]; hb[1] = ha[1]; }
-                else up_hwindow(c, *reinterpret_cast<const up_v4u*>(sc + (size_t)rt.y1 * w), hb);
+                else up_hwindow<NW>(c, up_load_window<NW>(sc + (size_t)rt.y1 * w), hb);
                 yb = rt.y1;
             }
             up_vblend_store(dc + (size_t)Y * W, c.live, rt.ly, ha, hb);
         }
     }
 }
-template <int ROWS>
+template <int ROWS, int NW>
 __device__ __forceinline__ void upsample_phased(const float* __restrict__ s, float* __restrict__ d, int h, int w, int H, int W, int q,
                                                 int Ya) {
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
     const unsigned g = up_line_unit(d) + (unsigned)Ya * (unsigned)(W >> 2);      // the row's first unit, mod 8 = its phase
-    const UpCol c = up_col_weights(q, (int)((8u - (g & 7u)) & 7u), w, W, sx);
+    const UpCol<NW> c = up_col_weights<NW>(q, (int)((8u - (g & 7u)) & 7u), w, W, sx);
     const float* sc = s + c.xs;
     float* dc = d + c.u * 4;
-    up_v4u ta[ROWS], tb[ROWS];
+    UpWin<NW> ta[ROWS], tb[ROWS];
     UpRow rt[ROWS];
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
         rt[j] = up_row_terms(min(Ya + 8 * j, H - 1), h, sy);
-        ta[j] = *reinterpret_cast<const up_v4u*>(sc + (size_t)rt[j].y0 * w);
-        tb[j] = *reinterpret_cast<const up_v4u*>(sc + (size_t)rt[j].y1 * w);
+        ta[j] = up_load_window<NW>(sc + (size_t)rt[j].y0 * w);
+        tb[j] = up_load_window<NW>(sc + (size_t)rt[j].y1 * w);
     }
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
         up_v2 ha[2], hb[2];
-        up_hwindow(c, ta[j], ha);
-        up_hwindow(c, tb[j], hb);
+        up_hwindow<NW>(c, ta[j], ha);
+        up_hwindow<NW>(c, tb[j], hb);
         const int Y = Ya + 8 * j;
         up_vblend_store(dc + (size_t)Y * W, c.live && Y < H, rt[j].ly, ha, hb);
     }
@@ -873,10 +897,10 @@ __device__ __forceinline__ UpPlane up_plane(const UpsampleMulti& m, int P, int h
     while (t < m.n - 1 && P >= m.planes[t]) { P -= m.planes[t]; ++t; }
     return UpPlane{m.src[t] + (size_t)P * h * w, m.dst[t] + (size_t)P * H * W};
 }
-enum { kUpScalar = 0, kUpGather = 1, kUpConsec = 2, kUpConsecPref = 3, kUpPhased = 4 };
-template <int MODE, int ROWS>
-__global__ __launch_bounds__(MODE == kUpPhased ? 512 : 256) void upsample_kernel(UpsampleMulti m, int total, int h, int w, int H, int W) {
-    if constexpr (MODE == kUpScalar) {
+enum { kUpScalar = 0, kUpGather = 1, kUpConsec = 2, kUpPhased = 3 };
+template <int KIND, int ROWS, int NW, int RMAX>
+__global__ __launch_bounds__(KIND == kUpPhased ? 512 : 256) void upsample_kernel(UpsampleMulti m, int total, int h, int w, int H, int W) {
+    if constexpr (KIND == kUpScalar) {
         for (int P = blockIdx.y; P < total; P += gridDim.y) {
             const UpPlane pl = up_plane(m, P, h, w, H, W);
             upsample_plane(pl.s, pl.d, h, w, H, W);
@@ -884,31 +908,38 @@ __global__ __launch_bounds__(MODE == kUpPhased ? 512 : 256) void upsample_kernel
     } else {
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const int q = blockIdx.x * 64 + (threadIdx.x & 63);
-        const int Y0 = MODE == kUpPhased ? blockIdx.y * (8 * ROWS) + wave : (blockIdx.y * 4 + wave) * ROWS;
+        const int Y0 = KIND == kUpPhased ? blockIdx.y * (8 * ROWS) + wave : (blockIdx.y * 4 + wave) * ROWS;
         if (Y0 >= H) return;
         for (int P = blockIdx.z; P < total; P += gridDim.z) {
             const UpPlane pl = up_plane(m, P, h, w, H, W);
-            if constexpr (MODE == kUpGather) upsample_gather<ROWS>(pl.s, pl.d, h, w, H, W, q, Y0);
-            else if constexpr (MODE == kUpPhased) upsample_phased<ROWS>(pl.s, pl.d, h, w, H, W, q, Y0);
-            else upsample_consec<ROWS, MODE == kUpConsecPref>(pl.s, pl.d, h, w, H, W, q, Y0);
+            if constexpr (KIND == kUpGather) upsample_gather<ROWS>(pl.s, pl.d, h, w, H, W, q, Y0);
+            else if constexpr (KIND == kUpPhased) upsample_phased<ROWS, NW>(pl.s, pl.d, h, w, H, W, q, Y0);
+            else upsample_consec<ROWS, NW, RMAX>(pl.s, pl.d, h, w, H, W, q, Y0);
         }
     }
 }
-// The four-float window holds every tap of four adjacent output pixels when x0[3] <= x0[0] + 2, i.e. 3 sx <= 2 in exact
-// arithmetic.  The kernel derives x0 from fp32 (X + 0.5) sx - 0.5, whose error per value is below fx 2^-23 <= w 2^-23;
-// two of them must not bridge the gap 2 - 3 w / W = (2 W - 3 w) / W, so away from the exact ratio 1.5 (where no source
-// coordinate of a lane's first pixel is an integer: (16 u - 1) / 6) the window path needs (2 W - 3 w) 2^21 > w W.
-__host__ inline bool upsample_window_ok(int w, int W) {
-    const long long gap = 2LL * W - 3LL * w;
-    return w >= 4 && (gap == 0 || (gap > 0 && (double)gap * 2097152.0 > (double)w * (double)W));
+// A window of NW source floats holds every tap of four adjacent output pixels when x0[3] <= x0[0] + NW - 2, i.e.
+// 3 sx <= NW - 2 in exact arithmetic (NW = 4: upsampling by >= 1.5; NW = 5: by >= 1).  The kernel derives x0 from fp32
+// (X + 0.5) sx - 0.5, whose error per value is below fx 2^-23 <= w 2^-23; two of them must not bridge the gap
+// (NW - 2) - 3 w / W = ((NW - 2) W - 3 w) / W, so away from the exact ratios (1.5: no source coordinate of a lane's first
+// pixel is an integer, (16 u - 1) / 6; 1: every coordinate is an exact integer) the window path needs gap 2^21 > w W.
+__host__ inline bool upsample_window_ok(int nw, int w, int W) {
+    const long long gap = (long long)(nw - 2) * W - 3LL * w;
+    return w >= nw && (gap == 0 || (gap > 0 && (double)gap * 2097152.0 > (double)w * (double)W));
 }
-__host__ inline int upsample_mode(const UpsampleMulti& m, int h, int w, int H, int W) {
+struct UpPlan { int kind, nw, pref; };      // pref: 0 none, 1 = 3 h <= 2 H (2 ROWS / 3 + 3 source rows), 2 = h <= H (ROWS + 2)
+__host__ inline UpPlan upsample_plan(const UpsampleMulti& m, int h, int w, int H, int W) {
     bool vec4 = W % 4 == 0;
     for (int t = 0; t < m.n; ++t) vec4 = vec4 && (reinterpret_cast<uintptr_t>(m.dst[t]) & 15u) == 0;
-    if (!vec4) return kUpScalar;
-    if (!upsample_window_ok(w, W)) return kUpGather;
-    if ((W / 4) % 8 != 0) return kUpPhased;
-    return 3LL * h <= 2LL * H ? kUpConsecPref : kUpConsec;
+    if (!vec4) return UpPlan{kUpScalar, 4, 0};
+    const int nw = upsample_window_ok(4, w, W) ? 4 : (upsample_window_ok(5, w, W) ? 5 : 0);
+    if (!nw) return UpPlan{kUpGather, 4, 0};
+    // Ragged = rows that are not a whole number of 64-BYTE half lines (W / 4 units of 16 B, not divisible by 4): only then do
+    // the wave stores of the consecutive-row kernel leave 16 ... 48-byte slivers.  Rows of 2240 B (560 px) alternate between
+    // line-aligned and 64 B off, and stream at full rate without rotation (5.9 TB/s against 4.0 through the phased kernel,
+    // which gives up the vertical reuse); rows of 6480 B (1620 px) need it (3.9 against 5.6).
+    if ((W / 4) % 4 != 0) return UpPlan{kUpPhased, nw, 0};
+    return UpPlan{kUpConsec, nw, 3LL * h <= 2LL * H ? 1 : (h <= H ? 2 : 0)};
 }
 
 // optimizer_step (lm_optimizer.py:109-137) as a batched device kernel: delta = (H + diag(clamp(lambda diag H, eps)))^-1 G
@@ -1089,18 +1120,19 @@ hipError_t launch_pblock_from_params(const SolveCtx& c, const float* d_cam, cons
 // Several tensors of (h, w) planes in ONE launch (the four tensors _post_process resizes: up 2 planes per image, latitude,
 // two confidences): a single-image calibrate() pays one launch instead of four.  Small jobs (one image) take half the
 // rows per wave: twice the waves to fill 256 CUs.
-template <int MODE>
-static void launch_upsample_mode(const UpsampleMulti& m, int total, int h, int w, int H, int W, bool small, hipStream_t s) {
+template <int KIND, int NW, int PREF>
+static void launch_upsample_kind(const UpsampleMulti& m, int total, int h, int w, int H, int W, bool small, hipStream_t s) {
     const int strips = (W / 4 + 63) / 64, gz = total < 65535 ? total : 65535;
-    if (small) {
-        constexpr int R = 4;
-        const dim3 grid(strips, MODE == kUpPhased ? (H + 8 * R - 1) / (8 * R) : (H + 4 * R - 1) / (4 * R), gz);
-        hipLaunchKernelGGL((upsample_kernel<MODE, R>), grid, dim3(MODE == kUpPhased ? 512 : 256), 0, s, m, total, h, w, H, W);
-    } else {
-        constexpr int R = 8;
-        const dim3 grid(strips, MODE == kUpPhased ? (H + 8 * R - 1) / (8 * R) : (H + 4 * R - 1) / (4 * R), gz);
-        hipLaunchKernelGGL((upsample_kernel<MODE, R>), grid, dim3(MODE == kUpPhased ? 512 : 256), 0, s, m, total, h, w, H, W);
-    }
+    auto go = [&](auto rows) {
+        constexpr int R = decltype(rows)::value;
+        constexpr int RMAX = PREF == 1 ? 2 * R / 3 + 3 : (PREF == 2 ? R + 2 : 0);
+        const dim3 grid(strips, KIND == kUpPhased ? (H + 8 * R - 1) / (8 * R) : (H + 4 * R - 1) / (4 * R), gz);
+        hipLaunchKernelGGL((upsample_kernel<KIND, R, NW, RMAX>), grid, dim3(KIND == kUpPhased ? 512 : 256), 0, s, m, total, h, w, H, W);
+    };
+    // one image: half the rows per wave, twice the waves for 256 CUs; the phased five-float window with 8 rows holds 16
+    // windows = 138 VGPRs, one 512-thread block per CU: 4 rows (90 VGPRs, two blocks) stream faster
+    if (small || (KIND == kUpPhased && NW == 5)) go(std::integral_constant<int, 4>{});
+    else go(std::integral_constant<int, 8>{});
 }
 hipError_t launch_upsample_multi(const UpsampleMulti& m, int h, int w, int H, int W, hipStream_t s) {
     long long total = 0;
@@ -1108,17 +1140,25 @@ hipError_t launch_upsample_multi(const UpsampleMulti& m, int h, int w, int H, in
     if (total == 0 || (size_t)H * W == 0) return hipSuccess;
     if (total > 0x7fffffffLL) return hipErrorInvalidValue;
     const bool small = (double)total * H * W < 16.0e6;
-    switch (upsample_mode(m, h, w, H, W)) {
-        case kUpScalar: {
-            unsigned bx = ((unsigned)H * (unsigned)W + 256 * 4 - 1) / (256 * 4);
-            hipLaunchKernelGGL((upsample_kernel<kUpScalar, 1>), dim3(bx < 1 ? 1 : bx, (unsigned)(total < 65535 ? total : 65535)), dim3(256), 0, s, m,
-                               (int)total, h, w, H, W);
-            break;
-        }
-        case kUpGather: launch_upsample_mode<kUpGather>(m, (int)total, h, w, H, W, small, s); break;
-        case kUpConsec: launch_upsample_mode<kUpConsec>(m, (int)total, h, w, H, W, small, s); break;
-        case kUpConsecPref: launch_upsample_mode<kUpConsecPref>(m, (int)total, h, w, H, W, small, s); break;
-        default: launch_upsample_mode<kUpPhased>(m, (int)total, h, w, H, W, small, s); break;
+    const int n = (int)total;
+    const UpPlan p = upsample_plan(m, h, w, H, W);
+    if (p.kind == kUpScalar) {
+        unsigned bx = ((unsigned)H * (unsigned)W + 256 * 4 - 1) / (256 * 4);
+        hipLaunchKernelGGL((upsample_kernel<kUpScalar, 1, 4, 0>), dim3(bx < 1 ? 1 : bx, (unsigned)(total < 65535 ? total : 65535)), dim3(256), 0, s, m, n,
+                           h, w, H, W);
+    } else if (p.kind == kUpGather) {
+        launch_upsample_kind<kUpGather, 4, 0>(m, n, h, w, H, W, small, s);
+    } else if (p.kind == kUpPhased) {
+        if (p.nw == 4) launch_upsample_kind<kUpPhased, 4, 0>(m, n, h, w, H, W, small, s);
+        else launch_upsample_kind<kUpPhased, 5, 0>(m, n, h, w, H, W, small, s);
+    } else if (p.nw == 4) {
+        if (p.pref == 1) launch_upsample_kind<kUpConsec, 4, 1>(m, n, h, w, H, W, small, s);
+        else if (p.pref == 2) launch_upsample_kind<kUpConsec, 4, 2>(m, n, h, w, H, W, small, s);
+        else launch_upsample_kind<kUpConsec, 4, 0>(m, n, h, w, H, W, small, s);
+    } else {
+        if (p.pref == 1) launch_upsample_kind<kUpConsec, 5, 1>(m, n, h, w, H, W, small, s);
+        else if (p.pref == 2) launch_upsample_kind<kUpConsec, 5, 2>(m, n, h, w, H, W, small, s);
+        else launch_upsample_kind<kUpConsec, 5, 0>(m, n, h, w, H, W, small, s);
     }
     return hipGetLastError();
 }
@@ -1134,7 +1174,8 @@ hipError_t launch_pack_fields(const float* up_raw, const float* up_lc, const flo
     if (B <= 0) return hipSuccess;
     const size_t N = (size_t)H * W;
     const size_t units = vec4 ? N / 4 : N;
-    const int bx = (int)((units + 255) / 256 < 128 ? (units + 255) / 256 : 128);
+    // one unit per thread and image where the image allows (one pass: +3 % over 128 blocks walking a grid-stride loop)
+    const int bx = (int)((units + 255) / 256 < 2048 ? (units + 255) / 256 : 2048);
     const dim3 grid(bx, B < 4096 ? B : 4096), block(256);
     if (vec4) hipLaunchKernelGGL(pack_fields_kernel<4>, grid, block, 0, s, up_raw, up_lc, lat_raw, lat_lc, B, N, up, upc, lat, latc);
     else hipLaunchKernelGGL(pack_fields_kernel<1>, grid, block, 0, s, up_raw, up_lc, lat_raw, lat_lc, B, N, up, upc, lat, latc);

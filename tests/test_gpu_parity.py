@@ -1061,7 +1061,15 @@ def test_randomised_configurations_against_oracle(dev, oracle):
                                    ((3, 9, 12), (27, 36)),              # ragged rows AND ragged planes (3888 B): a phase per plane
                                    ((2, 100, 64), (120, 160)),          # window in x, x1.2 in y: no prefetch of the source rows
                                    ((1, 8, 2048), (8, 3072)),           # exactly x1.5 on a wide row: the window path
-                                   ((1, 8, 2730), (16, 4096))])         # a hair under x1.5 at 4096 wide: fp32 cannot promise the window
+                                   ((1, 8, 2730), (16, 4096)),          # a hair under x1.5 at 4096 wide: fp32 cannot promise the 4-float window (the 5-float one holds)
+                                   ((2, 5, 320, 448), (400, 560)),      # x1.25: five-float window, rows of 17.5 lines (2240 B: half lines, no rotation)
+                                   ((2, 5, 320, 448), (400, 564)),      # x1.26: five-float window, ragged rows (2256 B): phase-rotated
+                                   ((9, 5, 300, 400), (375, 512)),      # x1.28 / x1.25: five-float window, whole lines, ROWS + 2 source rows prefetched
+                                   ((2, 300, 400), (375, 512)),         # ... one image's worth: 4 rows per wave
+                                   ((2, 48, 64), (48, 64)),             # the identity resize (exact copy)
+                                   ((2, 100, 64), (50, 160)),           # window in x, DOWNsampling in y: source rows loaded as the walk reaches them
+                                   ((1, 6, 7), (7, 8)),                 # a source row of barely one five-float window
+                                   ((1, 4, 4095), (4, 4096))])          # a hair under x1 at 4096 wide: per-lane gathers
 def test_upsample_fields_matches_torch_interpolate(dev, shape):
     """gclm_upsample_fields (GeoCalib._post_process, extractor.py:60-63) against F.interpolate bilinear."""
     from geocalib_amd.fields import upsample_fields
@@ -1072,6 +1080,8 @@ def test_upsample_fields_matches_torch_interpolate(dev, shape):
     out = upsample_fields(x, size)
     assert out.shape == ref.shape
     assert torch.allclose(out, ref, atol=2e-6, rtol=1e-6), (out - ref).abs().max().item()
+    if tuple(x.shape[-2:]) == tuple(size):
+        assert torch.equal(out, x)
 
 
 def test_upsample_paths_agree_bitwise(dev):
@@ -1082,7 +1092,10 @@ def test_upsample_paths_agree_bitwise(dev):
     lib = _lib.load()
     for (planes, h, w), (H, W) in (((10, 240, 320), (480, 640)), ((56, 240, 320), (480, 640)), ((3, 320, 480), (1080, 1620)),
                                    ((11, 320, 480), (1080, 1620)), ((3, 90, 120), (100, 160)), ((2, 100, 64), (120, 160)),
-                                   ((4, 9, 12), (27, 36)), ((1, 8, 2730), (16, 4096)), ((1, 8, 2048), (8, 3072))):
+                                   ((4, 9, 12), (27, 36)), ((1, 8, 2730), (16, 4096)), ((1, 8, 2048), (8, 3072)),
+                                   ((10, 320, 448), (400, 560)), ((3, 320, 448), (400, 560)), ((45, 300, 400), (375, 512)),
+                                   ((10, 320, 448), (400, 564)), ((3, 320, 448), (400, 564)),
+                                   ((3, 300, 400), (375, 512)), ((2, 48, 64), (48, 64)), ((2, 100, 64), (50, 160)), ((1, 4, 4095), (4, 4096))):
         x = torch.randn(planes, h, w, generator=torch.Generator().manual_seed(planes)).to(dev)
         vec = torch.full((planes * H * W,), float("nan"), device=dev)
         sca = torch.full((planes * H * W + 4,), float("nan"), device=dev)
