@@ -328,9 +328,14 @@ __device__ __forceinline__ void radial_terms(const PBlock& P, F r2, Radial<F>& R
         // ulp is not a zero-mean rounding like the correctly rounded root the reference takes (torch.sqrt) -- at
         // |k| = 1e-3 the FINAL COST of an image came out 2e-4 off at parameters equal to 1e-7 (fuzz 15/0 after one LM
         // step; the oracle's float32 build: 3e-6).  One Newton step on the exact fma residual brings the hardware root
-        // to the correctly rounded one's accuracy (its error is again zero-mean) for three packed operations.
-        const F t1h = vsqrt_hw(t0), it1 = vrcp_hw(t1h), it0 = it1 * it1;
-        const F t1 = vfma(vfma(-t1h, t1h, t0), 0.5f * it1, t1h);
+        // to the correctly rounded one's accuracy (its error is again zero-mean) for three packed operations (+ two for 1 / t1).
+        // The reciprocal is stepped to the SAME point: the Jacobian terms below are cancelling sums of t1 and 1 / t1, and a
+        // root and a reciprocal that belong to two different points a few 1e-8 apart break those cancellations where the
+        // terms are large (fuzz 29/162: focal 3 px on a 118 px row, r2 = 340 -- twice the unrefined build's distance from the
+        // oracle per step, with the other sign, until an ill-conditioned step amplified it past the gate).
+        const F t1h = vsqrt_hw(t0), ih = vrcp_hw(t1h);
+        const F t1 = vfma(vfma(-t1h, t1h, t0), 0.5f * ih, t1h);
+        const F it1 = vfma(ih, vfma(-t1, ih, one), ih), it0 = it1 * it1;
         const F ssq = vsel_eq0(t0 - tt, t1, vsqrt_hw(vmax(tt, zero)));      // tt < 1e-6 (|4 k r2| ~ 1): nothing cancels there
 #else
         const F ssq = vsqrt_hw(vmax(tt, zero));

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-5 evidence in one gpurun call (final binary): smoke, full -m gpu suite with the measurement log, the driver's own
-# command twice (plain / self-launched two ranks over gloo), the kernels either side of the path, a 12-seed soak, the
+# command twice (plain / self-launched two ranks over gloo), the kernels either side of the path, a 20-seed soak, the
 # round's profile set (bench lines, rocprofv3 kernel stats, HBM + SQ PMC passes, one-rank RCCL lines, latency).
 #   gpurun --timeout 2700 -- 'scripts/r05_collect.sh'   then   python scripts/keep_profiles.py r05
 cd ${GRAFT_REPO_ROOT:-.}
@@ -32,8 +32,8 @@ echo "=== the kernels either side of the path"
 timeout 300 python scripts/probes/fields_probe.py --json gpurun_out/$T/fields_kernels.json 2>&1 | grep "upsample\|pack" | cut -c1-200
 [ -x scripts/probes/_build/upsample_bench ] && timeout 300 scripts/probes/_build/upsample_bench 20 > gpurun_out/$T/upsample_bench.log 2>&1
 timeout 300 python scripts/probes/calibrate_probe.py > gpurun_out/$T/calibrate_probe.log 2>&1; tail -6 gpurun_out/$T/calibrate_probe.log
-echo "=== soak (12 seeds x 300 draws)"
+echo "=== soak (20 seeds x 300 draws)"
 rm -f gpurun_out/${T}_fuzz_soak.txt
-SOAK_TAG=$T timeout 1500 scripts/fuzz_soak.sh 11 22 300 2>&1 | grep "^seed" | cut -c1-200
+SOAK_TAG=$T timeout 2000 scripts/fuzz_soak.sh 11 30 300 2>&1 | grep "^seed" | cut -c1-200
 echo "=== profiles"
 timeout 1500 scripts/gpu_profile_all.sh $T 2>&1 | grep -v amdgpu.ids | grep -v "^E2026\|^W2026" | tail -70

@@ -1040,7 +1040,9 @@ def test_randomised_configurations_against_oracle(dev, oracle):
     assert sum(undetermined.values()) <= 0.3 * n_cases, undetermined
     for m in ALL_MODELS:          # no model's fuzz may degenerate into "finite only" (VERDICT r04 #4b); small samples: 80-draw runs
         if drawn[m] >= 10:
-            assert compared[m] >= 0.5, (m, compared, drawn, undetermined)
+            # at the END of the solve: 0.52 ... 0.76 of the simple_divisional draws over seeds 11-30 (0.556 for the committed seed,
+            # pinned by FUZZ_UNDETERMINED_2024 above); at the end OR after the first step: 0.97 ... 1.0 of every model's
+            assert compared[m] >= (0.5 if seed == 2024 else 0.4), (m, compared, drawn, undetermined)
             assert compared_any[m] >= 0.8, (m, compared_any, drawn, undetermined, first_step)
     if div is not None and seed in (2024, *range(11, 23)):
         assert against_reference >= 5, against_reference      # simple_divisional really was drawn and TIGHTLY gated by the reference
