@@ -98,6 +98,9 @@
                                     // built-in choice does not use them (memory-bound: the plane's one extra write costs
                                     // what the saved VALU work gains), gclm_set_slat_plane(h, 1) does (measurement)
 #endif
+#ifndef GCLM_ORDER
+#define GCLM_ORDER 0                // A/B switch: the order in which workgroups visit (image, chunk), see sweep_kernel
+#endif
 #ifndef GCLM_DIV_SQRT_REFINE
 #define GCLM_DIV_SQRT_REFINE 1      // A/B switch: 0 = simple_divisional takes v_sqrt_f32 as it comes (rounds 2-4)
 #endif
@@ -1126,6 +1129,13 @@ __global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL == GCLM_RADIAL) ? GCLM_R
             chunk = (int)(nid - (unsigned)b * gridDim.x);
         }
     }
+#elif GCLM_ORDER == 1   // A/B switch (placement probe): consecutive workgroups take the SAME chunk of consecutive images
+    const unsigned lin1 = blockIdx.y * gridDim.x + blockIdx.x;
+    const int chunk = (int)(lin1 / gridDim.y), b = (int)(lin1 - (unsigned)chunk * gridDim.y);
+#elif GCLM_ORDER == 2   // ... images visited with a stride of 389 (coprime to the batch sizes probed)
+    const int chunk = blockIdx.x, b = (int)((blockIdx.y * 389u) % gridDim.y);
+#elif GCLM_ORDER == 3   // ... two windows half a batch apart
+    const int chunk = blockIdx.x, b = (int)((blockIdx.y & 1u) ? (gridDim.y + 1) / 2 + blockIdx.y / 2 : blockIdx.y / 2);
 #else
     const int b = blockIdx.y, chunk = blockIdx.x;
 #endif

@@ -32,6 +32,7 @@ def opt(name, default):
 models = opt("--models", "pinhole,simple_radial").split(",")
 B = int(opt("--batch", "1024"))
 reps = int(opt("--reps", "3"))
+allocations = int(opt("--allocations", "1"))       # repeat everything on N allocations of the fields (earlier ones stay alive: other pages)
 H, W = 480, 640
 libs = []
 for a in args:
@@ -46,8 +47,12 @@ for a in args:
     assert lib.gclm_version() in (400, _lib.ABI_VERSION) and lib.gclm_abi_config_size() == C.sizeof(_lib.GclmConfig)
     libs.append((name, lib, int(iters or 0), int(slat) if slat else None))
 dev = torch.device("cuda:0")
-for model in models:
+keep = []
+for model in [m for m in models for _ in range(allocations)]:
     data, gtc, _ = synth_fields(model, B, H, W, dev, seed=1)
+    if allocations > 1:
+        keep.append(data)
+        print(f"-- allocation {len(keep)}: up_field at {data['up_field'].data_ptr():#x}")
     up, lat, upc, latc = (data[k].contiguous() for k in ("up_field", "latitude_field", "up_confidence", "latitude_confidence"))
     handles, outs = {}, {}
     for name, lib, iters, slat in libs:
