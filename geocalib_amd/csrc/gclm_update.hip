@@ -679,9 +679,9 @@ __device__ __forceinline__ void upsample_plane(const float* __restrict__ s, floa
 //     line: every full wave store then starts on a line.  Rows of 1620 floats (6480 B) are not whole lines; round 4
 //     wrote each wave's 1 KiB across nine lines, two of them partial, and the stores alone took 1.75x a flat fill
 //     (profiles/r05_upsample_bench.log: 652 -> 439 us for 64 x 5 planes 320x480 -> 1080x1620).
-//   * CONSEC (rows are whole 64-byte half lines, Wu % 4 == 0): a wave walks ROWS consecutive output rows; every source row it needs is
-//     loaded up front (PREF, when the vertical ratio bounds their number) and its horizontally interpolated values stay in
-//     registers for all output rows that tap it.
+//   * CONSEC (rows are whole 64-byte half lines, Wu % 4 == 0): a wave walks ROWS consecutive output rows; every source
+//     row it needs is loaded up front (RMAX, when the vertical ratio bounds their number) and its horizontally interpolated
+//     values stay in registers for all output rows that tap it.
 //   * PHASED (ragged rows): rows 8 apart share the phase o (8 Wu = 0 mod 8 units), so wave i of a 512-thread block owns
 //     rows Y0 + i + 8 j and keeps its column weights; all 2 ROWS window loads are issued before the arithmetic.
 //   * GATHER (any other ratio): per-lane dword gathers, consecutive rows, no rotation.
