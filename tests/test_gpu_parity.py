@@ -1109,6 +1109,20 @@ def test_upsample_paths_agree_bitwise(dev):
         assert torch.equal(vec, sca[1:-3]), ((planes, h, w), (H, W), (vec - sca[1:-3]).abs().max().item())
 
 
+def test_upsample_more_planes_than_a_grid_dimension(dev):
+    """Beyond 65 535 planes the launch strides over them (grid.z of the float4 kernels, grid.y of the scalar one); the
+    multi-tensor entry point no longer has a plane limit."""
+    import torch.nn.functional as F
+    from geocalib_amd.fields import upsample_fields, upsample_fields_multi
+    x = torch.randn(70001, 4, 8, generator=torch.Generator().manual_seed(3)).to(dev)
+    for size in ((8, 16), (7, 15)):                     # float4 window path / scalar path (15 is not a multiple of 4)
+        ref = F.interpolate(x[:, None], size=size, mode="bilinear")[:, 0]
+        out = upsample_fields(x, size)
+        assert torch.allclose(out, ref, atol=2e-6, rtol=1e-6), (size, (out - ref).abs().max().item())
+    a, b = upsample_fields_multi([x[:40000], x[40000:]], (8, 16))
+    assert torch.equal(torch.cat([a, b]), upsample_fields(x, (8, 16)))
+
+
 def test_upsample_multi_ragged_planes(dev):
     """gclm_upsample_fields_multi on tensors whose planes are not whole 128-byte lines: the store rotation takes its phase
     from every plane's own address."""
