@@ -1109,6 +1109,36 @@ def test_upsample_paths_agree_bitwise(dev):
         assert torch.equal(vec, sca[1:-3]), ((planes, h, w), (H, W), (vec - sca[1:-3]).abs().max().item())
 
 
+def test_upsample_random_shapes_agree_with_the_scalar_kernel(dev):
+    """Seeded fuzz over shapes: every float4 kernel the plan can pick (windows of 4 / 5 floats, consecutive / phase-rotated
+    rows, 4 / 8 rows per wave, three prefetch depths, gathers) against the scalar kernel bit for bit, and against
+    F.interpolate at 2e-6.  Ratios from 0.4 to 6, widths around the strip (256 px) and line (32 px) boundaries, 1-40 planes."""
+    import torch.nn.functional as F
+    from geocalib_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(20260924)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    seen = set()
+    for it in range(160):
+        W = int(rng.choice([8, 12, 36, 64, 100, 128, 252, 256, 260, 516, 640, 1000, 1620])) if it % 3 else 4 * int(rng.integers(1, 420))
+        H = int(rng.integers(1, 70))
+        rx, ry = float(rng.choice([0.4, 0.9, 1.0, 1.1, 1.25, 1.49, 1.5, 1.51, 2.0, 3.375, 6.0])), float(rng.choice([0.5, 1.0, 1.2, 1.5, 2.0, 4.0]))
+        w, h = max(1, int(round(W / rx))), max(1, int(round(H / ry)))
+        planes = int(rng.choice([1, 2, 5, 40])) if W * H < 20000 else int(rng.choice([1, 5]))
+        if rng.random() < 0.1:
+            planes = 1 + int(16.0e6 // (H * W))               # past the "small job" cut: 8 rows per wave
+        x = torch.randn(planes, h, w, generator=torch.Generator().manual_seed(it)).to(dev)
+        vec = torch.full((planes * H * W,), float("nan"), device=dev)
+        sca = torch.full((planes * H * W + 4,), float("nan"), device=dev)
+        assert lib.gclm_upsample_fields(x.data_ptr(), planes, h, w, H, W, vec.data_ptr(), stream) == 0
+        assert lib.gclm_upsample_fields(x.data_ptr(), planes, h, w, H, W, sca.data_ptr() + 4, stream) == 0
+        assert torch.equal(vec, sca[1:-3]), ((planes, h, w), (H, W), (vec - sca[1:-3]).abs().max().item())
+        ref = F.interpolate(x[:, None], size=(H, W), mode="bilinear")[:, 0].reshape(-1)
+        assert torch.allclose(vec, ref, atol=2e-6, rtol=1e-6), ((planes, h, w), (H, W), (vec - ref).abs().max().item())
+        seen.add((w >= 4 and 3 * w <= 2 * W, w >= 5 and w <= W, (W // 4) % 4 == 0, 3 * h <= 2 * H, h <= H, planes * H * W >= 16.0e6))
+    assert len(seen) >= 20, len(seen)                       # the draws really spread over the plan's branches
+
+
 def test_upsample_more_planes_than_a_grid_dimension(dev):
     """Beyond 65 535 planes the launch strides over them (grid.z of the float4 kernels, grid.y of the scalar one); the
     multi-tensor entry point no longer has a plane limit."""
