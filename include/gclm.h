@@ -343,7 +343,8 @@ int gclm_set_sweep_iters(gclm_handle* h, int iters);
  * partial records, so two calls agree bit for bit on an image exactly when their cuts agree; a caller that solves ONE
  * batch in several parts (gclm_merge_stop_at; LMOptimizer.overlap_streams) asks here instead of mirroring the rule.  The
  * cut depends on the batch size only below 2048 chunks per call (small batches take fewer rows per chunk to fill the
- * GPU).  Either output pointer may be NULL.  No device work. */
+ * GPU).  Either output pointer may be NULL.  No device work, no error message: -1 for a NULL handle, -3 for a
+ * non-positive B, H or W. */
 int gclm_plan_cut(const gclm_handle* h, int B, int H, int W, int aligned16, int* rows_per_chunk, int* chunks_per_image);
 
 /* sin(latitude_field) (lm_optimizer.py:262,270) does not depend on the parameters, yet each of the num_steps + 1 sweeps of
