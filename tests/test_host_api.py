@@ -115,6 +115,30 @@ def test_distortion_jacobians_match_autograd(model):
         assert torch.allclose(c.up_projection_offset(pts[b:b + 1])[0], Js, atol=1e-7), model
 
 
+@pytest.mark.parametrize("model", MODELS)
+def test_distort_and_undistort_accept_both_reference_keywords(model):
+    """The reference names the argument `pts` on BaseCamera.distort / undistort (camera.py:212,242) and `p2d` on the
+    distortion models (camera.py:611,631,712,737,829,863; Pinhole: distort(p2d), undistort(pts)).  One body serves the
+    distortion models here, so both keywords and the positional form give the same result; passing none or both is an error."""
+    cam, _ = make(model)
+    pts = (torch.rand(3, 10, 2, dtype=torch.float64, generator=torch.Generator().manual_seed(7)) - 0.5) * 0.8
+    d0, v0 = cam.distort(pts)
+    u0, w0 = cam.undistort(pts)
+    if model == "pinhole":
+        assert torch.equal(cam.distort(p2d=pts)[0], d0) and torch.equal(cam.undistort(pts=pts)[0], u0)
+        assert torch.equal(d0, pts) and torch.equal(u0, pts)
+        return
+    for kw in ("pts", "p2d"):
+        d, v = cam.distort(**{kw: pts})
+        u, w = cam.undistort(**{kw: pts})
+        assert torch.equal(d, d0) and torch.equal(v, v0) and torch.equal(u, u0) and torch.equal(w, w0), (model, kw)
+        assert torch.equal(cam.distort(return_scale=True, **{kw: pts})[0], cam.distort(pts, True)[0])
+    with pytest.raises(TypeError):
+        cam.distort()
+    with pytest.raises(TypeError):
+        cam.undistort(pts, p2d=pts)
+
+
 @pytest.mark.parametrize("model", MODELS[1:])
 def test_up_projection_offset_jacobians(model):
     """J_up_projection_offset / J_distort(scale2dist): the closed forms of the polynomial models and the generic
