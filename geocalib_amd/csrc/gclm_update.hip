@@ -681,7 +681,8 @@ __device__ __forceinline__ void upsample_plane(const float* __restrict__ s, floa
 //     (profiles/r05_upsample_bench.log: 652 -> 439 us for 64 x 5 planes 320x480 -> 1080x1620).
 //   * CONSEC (rows are whole 64-byte half lines, Wu % 4 == 0): a wave walks ROWS consecutive output rows; every source
 //     row it needs is loaded up front (RMAX, when the vertical ratio bounds their number) and its horizontally interpolated
-//     values stay in registers for all output rows that tap it.
+//     values stay in registers for all output rows that tap it.  The (up to four) waves of a block take adjacent strips
+//     of the same rows, so that a block writes whole rows.
 //   * PHASED (ragged rows): rows 8 apart share the phase o (8 Wu = 0 mod 8 units), so wave i of a 512-thread block owns
 //     rows Y0 + i + 8 j and keeps its column weights; all 2 ROWS window loads are issued before the arithmetic.
 //   * GATHER (any other ratio): per-lane dword gathers, consecutive rows, no rotation.
@@ -907,9 +908,13 @@ __global__ __launch_bounds__(KIND == kUpPhased ? 512 : 256) void upsample_kernel
         }
     } else {
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        const int q = blockIdx.x * 64 + (threadIdx.x & 63);
-        const int Y0 = KIND == kUpPhased ? blockIdx.y * (8 * ROWS) + wave : (blockIdx.y * 4 + wave) * ROWS;
-        if (Y0 >= H) return;
+        // CONSEC: the waves of a block take ADJACENT strips of the same ROWS rows -- a block writes whole rows (of up to
+        // 1024 px), row after row, instead of four row groups of one strip: 0.346 -> 0.323 ms on the x2 case
+        // (profiles/r05_upsample_bench.log, "rowblock").  The other kinds: blockIdx.x = strip, waves = row groups / phases.
+        const int strip = KIND == kUpConsec ? blockIdx.x * 4 + wave : blockIdx.x;
+        const int q = strip * 64 + (threadIdx.x & 63);
+        const int Y0 = KIND == kUpPhased ? blockIdx.y * (8 * ROWS) + wave : (KIND == kUpConsec ? blockIdx.y * ROWS : (blockIdx.y * 4 + wave) * ROWS);
+        if (Y0 >= H || strip * 64 >= (W >> 2)) return;
         for (int P = blockIdx.z; P < total; P += gridDim.z) {
             const UpPlane pl = up_plane(m, P, h, w, H, W);
             if constexpr (KIND == kUpGather) upsample_gather<ROWS>(pl.s, pl.d, h, w, H, W, q, Y0);
@@ -1126,8 +1131,14 @@ static void launch_upsample_kind(const UpsampleMulti& m, int total, int h, int w
     auto go = [&](auto rows) {
         constexpr int R = decltype(rows)::value;
         constexpr int RMAX = PREF == 1 ? 2 * R / 3 + 3 : (PREF == 2 ? R + 2 : 0);
-        const dim3 grid(strips, KIND == kUpPhased ? (H + 8 * R - 1) / (8 * R) : (H + 4 * R - 1) / (4 * R), gz);
-        hipLaunchKernelGGL((upsample_kernel<KIND, R, NW, RMAX>), grid, dim3(KIND == kUpPhased ? 512 : 256), 0, s, m, total, h, w, H, W);
+        if constexpr (KIND == kUpConsec) {
+            const int waves = strips < 4 ? strips : 4;            // 640 px: 2.5 strips = 3 waves per block, no idle wave
+            hipLaunchKernelGGL((upsample_kernel<KIND, R, NW, RMAX>), dim3((strips + 3) / 4, (H + R - 1) / R, gz), dim3(64 * waves), 0, s, m, total,
+                               h, w, H, W);
+        } else {
+            const dim3 grid(strips, KIND == kUpPhased ? (H + 8 * R - 1) / (8 * R) : (H + 4 * R - 1) / (4 * R), gz);
+            hipLaunchKernelGGL((upsample_kernel<KIND, R, NW, RMAX>), grid, dim3(KIND == kUpPhased ? 512 : 256), 0, s, m, total, h, w, H, W);
+        }
     };
     // one image: half the rows per wave, twice the waves for 256 CUs; the phased five-float window with 8 rows holds 16
     // windows = 138 VGPRs, one 512-thread block per CU: 4 rows (90 VGPRs, two blocks) stream faster

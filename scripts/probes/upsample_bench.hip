@@ -290,6 +290,18 @@ __global__ __launch_bounds__(256) void k2_consec(const float* __restrict__ src, 
     for (int p = blockIdx.z; p < planes; p += gridDim.z)
         strip2_consec<ROWS, PREF, PLAIN>(src + (size_t)p * h * w, dst + (size_t)p * H * W, h, w, H, W, q, Y0);
 }
+// ROWBLOCK: the four waves of a block take four ADJACENT strips of the same ROWS rows (a block writes whole rows of up to
+// 1024 px, row after row) instead of four row groups of one strip
+template <int ROWS, bool PREF, bool PLAIN>
+__global__ __launch_bounds__(256) void k2_rowblock(const float* __restrict__ src, int planes, int h, int w, int H, int W, float* __restrict__ dst) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = (blockIdx.x * 4 + wave) * 64 + (threadIdx.x & 63), Y0 = blockIdx.y * ROWS;
+    if ((blockIdx.x * 4 + wave) * 64 >= (W >> 2)) return;
+    for (int p = blockIdx.z; p < planes; p += gridDim.z)
+        strip2_consec<ROWS, PREF, PLAIN>(src + (size_t)p * h * w, dst + (size_t)p * H * W, h, w, H, W, q, Y0);
+}
+template <int ROWS, bool PREF, bool PLAIN>
+void launch2_rowblock(const Shape& g, const float* s, float* d, int, hipStream_t st);
 // PHASED: wave i of a 512-thread block owns rows Y0 + i + 8 j (j < ROWS): equal phase, so the column weights are shared
 template <int ROWS, bool PLAIN>
 __global__ __launch_bounds__(512) void k2_phased(const float* __restrict__ src, int planes, int h, int w, int H, int W, float* __restrict__ dst) {
@@ -323,6 +335,45 @@ __global__ __launch_bounds__(512) void k2_phased(const float* __restrict__ src, 
         }
     }
 }
+// PHASED + ROWBLOCK: 8 waves = 2 rows x 4 adjacent strips; the wave owns rows Ya + 8 j like k2_phased
+template <int ROWS, bool PLAIN, int SW>      // SW: strips per block (4 with 2 rows per block, 8 with 1)
+__global__ __launch_bounds__(512) void k2_phased_rb(const float* __restrict__ src, int planes, int h, int w, int H, int W, float* __restrict__ dst) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int RW = 8 / SW;                               // rows (phases) per block
+    const int strip = blockIdx.x * SW + (wave % SW), r = wave / SW;
+    const int groups = 8 / RW;                               // blocks along y that together cover the 8 phases
+    const int Ya = (blockIdx.y / groups) * (8 * ROWS) + (blockIdx.y % groups) * RW + r;
+    if (strip * 64 >= (W >> 2) || Ya >= H) return;
+    const int q = strip * 64 + (threadIdx.x & 63);
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    const int Wu = W >> 2;
+    for (int p = blockIdx.z; p < planes; p += gridDim.z) {
+        const float* s = src + (size_t)p * h * w;
+        float* d = dst + (size_t)p * H * W;
+        const unsigned g = (unsigned)((reinterpret_cast<uintptr_t>(d) >> 4) & 7u) + (unsigned)Ya * (unsigned)Wu;
+        const ColW c = col_weights(q, (int)((8u - (g & 7u)) & 7u), w, W, sx);
+        const float* sc = s + c.xs;
+        float* dc = d + c.u * 4;
+        v4u ta[ROWS], tb[ROWS];
+        RowT rt[ROWS];
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            rt[j] = row_terms(min(Ya + 8 * j, H - 1), h, sy);
+            ta[j] = *reinterpret_cast<const v4u*>(sc + (size_t)rt[j].y0 * w);
+            tb[j] = *reinterpret_cast<const v4u*>(sc + (size_t)rt[j].y1 * w);
+        }
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            v2f ha[2], hb[2];
+            hinterp2(c, ta[j], ha);
+            hinterp2(c, tb[j], hb);
+            const int Y = Ya + 8 * j;
+            vblend_store<PLAIN>(dc + (size_t)Y * W, c.live && Y < H, rt[j].ly, ha, hb);
+        }
+    }
+}
+template <int ROWS, bool PLAIN, int SW>
+void launch2_phased_rb(const Shape& g, const float* s, float* d, int, hipStream_t st);
 template <int ROWS, bool PREF, bool PLAIN>
 void launch2_consec(const Shape& g, const float* s, float* d, int, hipStream_t st);
 template <int ROWS, bool PLAIN>
@@ -386,6 +437,17 @@ void launch2_consec(const Shape& g, const float* s, float* d, int, hipStream_t s
     const dim3 grid((g.W / 4 + 63) / 64, (g.H + 4 * ROWS - 1) / (4 * ROWS), g.planes < 65535 ? g.planes : 65535);
     hipLaunchKernelGGL((k2_consec<ROWS, PREF, PLAIN>), grid, dim3(256), 0, st, s, g.planes, g.h, g.w, g.H, g.W, d);
 }
+template <int ROWS, bool PLAIN, int SW>
+void launch2_phased_rb(const Shape& g, const float* s, float* d, int, hipStream_t st) {
+    const int groups = SW;      // 8 / (8 / SW)
+    const dim3 grid((g.W / 4 + 64 * SW - 1) / (64 * SW), ((g.H + 8 * ROWS - 1) / (8 * ROWS)) * groups, g.planes < 65535 ? g.planes : 65535);
+    hipLaunchKernelGGL((k2_phased_rb<ROWS, PLAIN, SW>), grid, dim3(512), 0, st, s, g.planes, g.h, g.w, g.H, g.W, d);
+}
+template <int ROWS, bool PREF, bool PLAIN>
+void launch2_rowblock(const Shape& g, const float* s, float* d, int, hipStream_t st) {
+    const dim3 grid((g.W / 4 + 255) / 256, (g.H + ROWS - 1) / ROWS, g.planes < 65535 ? g.planes : 65535);
+    hipLaunchKernelGGL((k2_rowblock<ROWS, PREF, PLAIN>), grid, dim3(256), 0, st, s, g.planes, g.h, g.w, g.H, g.W, d);
+}
 template <int ROWS, bool PLAIN>
 void launch2_phased(const Shape& g, const float* s, float* d, int, hipStream_t st) {
     const dim3 grid((g.W / 4 + 63) / 64, (g.H + 8 * ROWS - 1) / (8 * ROWS), g.planes < 65535 ? g.planes : 65535);
@@ -419,6 +481,14 @@ int main(int argc, char** argv) {
         {"v2 consec4", launch2_consec<4, false, false>, 0},
         {"v2 consec4 pref", launch2_consec<4, true, false>, 0},
         {"v2 consec16 pref", launch2_consec<16, true, false>, 0},
+        {"v2 rowblock8 pref", launch2_rowblock<8, true, false>, 0},
+        {"v2 rowblock4 pref", launch2_rowblock<4, true, false>, 0},
+        {"v2 rowblock2 pref", launch2_rowblock<2, true, false>, 0},
+        {"v2 rowblock4 pref plain", launch2_rowblock<4, true, true>, 0},
+        {"v2 phased_rb4 x4strips", launch2_phased_rb<4, false, 4>, 0},
+        {"v2 phased_rb8 x4strips", launch2_phased_rb<8, false, 4>, 0},
+        {"v2 phased_rb4 x8strips", launch2_phased_rb<4, false, 8>, 0},
+        {"v2 phased_rb8 x8strips", launch2_phased_rb<8, false, 8>, 0},
         {"v2 phased2", launch2_phased<2, false>, 0},
         {"v2 phased4", launch2_phased<4, false>, 0},
         {"v2 phased4 plain", launch2_phased<4, true>, 0},
