@@ -900,7 +900,8 @@ __device__ __forceinline__ UpPlane up_plane(const UpsampleMulti& m, int P, int h
 }
 enum { kUpScalar = 0, kUpGather = 1, kUpConsec = 2, kUpPhased = 3 };
 template <int KIND, int ROWS, int NW, int RMAX>
-__global__ __launch_bounds__(KIND == kUpPhased ? 512 : 256) void upsample_kernel(UpsampleMulti m, int total, int h, int w, int H, int W) {
+__global__ __launch_bounds__(KIND == kUpPhased ? 512 : 256) void upsample_kernel(UpsampleMulti m, int total, int h, int w, int H, int W,
+                                                                                  int rowblock) {
     if constexpr (KIND == kUpScalar) {
         for (int P = blockIdx.y; P < total; P += gridDim.y) {
             const UpPlane pl = up_plane(m, P, h, w, H, W);
@@ -911,9 +912,11 @@ __global__ __launch_bounds__(KIND == kUpPhased ? 512 : 256) void upsample_kernel
         // CONSEC: the waves of a block take ADJACENT strips of the same ROWS rows -- a block writes whole rows (of up to
         // 1024 px), row after row, instead of four row groups of one strip: 0.346 -> 0.323 ms on the x2 case
         // (profiles/r05_upsample_bench.log, "rowblock").  The other kinds: blockIdx.x = strip, waves = row groups / phases.
-        const int strip = KIND == kUpConsec ? blockIdx.x * 4 + wave : blockIdx.x;
+        // (one image: the old grouping, four row groups of one strip per block -- 4.5 against 5.5 us for 5 planes of 480x640)
+        const bool rb = KIND == kUpConsec && rowblock != 0;
+        const int strip = rb ? blockIdx.x * 4 + wave : blockIdx.x;
         const int q = strip * 64 + (threadIdx.x & 63);
-        const int Y0 = KIND == kUpPhased ? blockIdx.y * (8 * ROWS) + wave : (KIND == kUpConsec ? blockIdx.y * ROWS : (blockIdx.y * 4 + wave) * ROWS);
+        const int Y0 = KIND == kUpPhased ? blockIdx.y * (8 * ROWS) + wave : (rb ? blockIdx.y * ROWS : (blockIdx.y * 4 + wave) * ROWS);
         if (Y0 >= H || strip * 64 >= (W >> 2)) return;
         for (int P = blockIdx.z; P < total; P += gridDim.z) {
             const UpPlane pl = up_plane(m, P, h, w, H, W);
@@ -1131,13 +1134,13 @@ static void launch_upsample_kind(const UpsampleMulti& m, int total, int h, int w
     auto go = [&](auto rows) {
         constexpr int R = decltype(rows)::value;
         constexpr int RMAX = PREF == 1 ? 2 * R / 3 + 3 : (PREF == 2 ? R + 2 : 0);
-        if constexpr (KIND == kUpConsec) {
+        if (KIND == kUpConsec && !small) {
             const int waves = strips < 4 ? strips : 4;            // 640 px: 2.5 strips = 3 waves per block, no idle wave
             hipLaunchKernelGGL((upsample_kernel<KIND, R, NW, RMAX>), dim3((strips + 3) / 4, (H + R - 1) / R, gz), dim3(64 * waves), 0, s, m, total,
-                               h, w, H, W);
+                               h, w, H, W, 1);
         } else {
             const dim3 grid(strips, KIND == kUpPhased ? (H + 8 * R - 1) / (8 * R) : (H + 4 * R - 1) / (4 * R), gz);
-            hipLaunchKernelGGL((upsample_kernel<KIND, R, NW, RMAX>), grid, dim3(KIND == kUpPhased ? 512 : 256), 0, s, m, total, h, w, H, W);
+            hipLaunchKernelGGL((upsample_kernel<KIND, R, NW, RMAX>), grid, dim3(KIND == kUpPhased ? 512 : 256), 0, s, m, total, h, w, H, W, 0);
         }
     };
     // one image: half the rows per wave, twice the waves for 256 CUs; the phased five-float window with 8 rows holds 16
@@ -1156,7 +1159,7 @@ hipError_t launch_upsample_multi(const UpsampleMulti& m, int h, int w, int H, in
     if (p.kind == kUpScalar) {
         unsigned bx = ((unsigned)H * (unsigned)W + 256 * 4 - 1) / (256 * 4);
         hipLaunchKernelGGL((upsample_kernel<kUpScalar, 1, 4, 0>), dim3(bx < 1 ? 1 : bx, (unsigned)(total < 65535 ? total : 65535)), dim3(256), 0, s, m, n,
-                           h, w, H, W);
+                           h, w, H, W, 0);
     } else if (p.kind == kUpGather) {
         launch_upsample_kind<kUpGather, 4, 0>(m, n, h, w, H, W, small, s);
     } else if (p.kind == kUpPhased) {
