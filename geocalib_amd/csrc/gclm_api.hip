@@ -47,7 +47,14 @@ struct gclm_handle {
         Geometry geo{};
         bool slat_ready = false;    // the scratch plane holds sin(latitude) of this session's fields
     } sh;
-    float* slat = nullptr;          // carved view: scratch plane (B, H, W) of sin(latitude_field), or null (see slat_wanted)
+    // The sin(latitude) scratch plane is an allocation of its own, of exactly the size asked for (no headroom), and the only
+    // part of the workspace a solve can do without: see ensure_slat.
+    float* slat_buf = nullptr;      // owned: (slat_bytes / 4) floats, or null
+    size_t slat_bytes = 0;
+    size_t slat_refused = 0;        // smallest plane size (bytes) whose allocation failed or was refused by the limit since the
+                                    // last change of the limit / mode: such a size is not tried again on every solve
+    size_t slat_limit = 0;          // gclm_set_slat_plane_limit: 0 = built-in rule (half of the free device memory), else bytes
+    float* slat = nullptr;          // the plane of the CURRENT solve / session (== slat_buf), or null: sweeps compute sin(latitude)
     int slat_plane = -1;            // gclm_set_slat_plane: -1 = built-in choice, 0 = never, 1 = wherever the sweep has it
     int sweep_iters = 0;            // gclm_set_sweep_iters: 0 = built-in choice
     int fused_mode = -1;            // gclm_set_fused_steps: -1 = built-in choice, 0 = never, 1 = whenever it is valid
@@ -128,10 +135,10 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 bool is_aligned16(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// Carve the workspace for B images / nchunks partial records per image / G groups, plus `slat_floats` floats of
-// scratch plane (0: none).  Growing it frees and re-allocates (hipFree synchronises the device ONCE, on the first call
-// of a larger shape than any before; every later call finds the workspace in place -- include/gclm.h says so).
-int ensure_workspace(gclm_handle* h, int B, int nchunks, int G, size_t slat_floats = 0) {
+// Carve the core workspace for B images / nchunks partial records per image / G groups.  Growing it frees and re-allocates
+// (hipFree synchronises the device ONCE, on the first call of a larger shape than any before; every later call finds the
+// workspace in place -- include/gclm.h says so).  A failure here is the only allocation failure a solve reports (-10).
+int ensure_workspace(gclm_handle* h, int B, int nchunks, int G) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_state0 = take(sizeof(State) * B), o_state1 = take(sizeof(State) * B);
@@ -141,12 +148,12 @@ int ensure_workspace(gclm_handle* h, int B, int nchunks, int G, size_t slat_floa
     const size_t o_fsys = take(sizeof(float) * kNAccMax * (size_t)B);
     const size_t o_gp = take(sizeof(float) * GCLM_SHARED_PARTIAL_STRIDE * (size_t)(G > 0 ? G : 1));
     const size_t o_ctrl = take(sizeof(Ctrl));
-    const size_t o_slat = take(sizeof(float) * slat_floats);
     if (off > h->ws_bytes) {
         if (h->ws) GCLM_HIP(h, hipFree(h->ws));
         h->ws = nullptr;
         h->ws_bytes = 0;
-        const size_t want = off + off / 4;      // headroom: no reallocation for slightly larger calls
+        const size_t want = off + off / 4;      // headroom: no reallocation for slightly larger calls (small records only:
+                                                // 3 MB at 1024 images of 640x480; the scratch plane is NOT in here)
         GCLM_HIP(h, hipMalloc(&h->ws, want));
         h->ws_bytes = want;
     }
@@ -162,8 +169,41 @@ int ensure_workspace(gclm_handle* h, int B, int nchunks, int G, size_t slat_floa
     c.frame_sys = reinterpret_cast<float*>(base + o_fsys);
     c.ctrl = reinterpret_cast<Ctrl*>(base + o_ctrl);
     h->group_partials = reinterpret_cast<float*>(base + o_gp);
-    h->slat = slat_floats ? reinterpret_cast<float*>(base + o_slat) : nullptr;
     return 0;
+}
+
+// The sin(latitude) scratch plane of a solve of `floats` pixels (0: none wanted): h->slat = the plane, or null when the solve
+// runs without it -- never an error.  The plane only saves arithmetic (gclm_pass.hip: row_math, SLAT); a sweep that computes
+// sin(latitude) itself produces the same bits, so whenever the plane cannot be had -- hipMalloc fails, or the plane is larger
+// than the limit (gclm_set_slat_plane_limit; built-in: half of the device memory that is free once the old plane is
+// released) -- the solve goes on without it, as the library did before it had the plane.  Exact size, no headroom: the plane
+// is 400x the rest of the workspace.  A size that was refused is remembered (slat_refused) so that a serving loop does not
+// pay a failing hipMalloc (and its device synchronisation) per call.
+void ensure_slat(gclm_handle* h, size_t floats) {
+    h->slat = nullptr;
+    if (floats == 0) return;
+    const size_t bytes = floats * sizeof(float);
+    if (bytes <= h->slat_bytes) { h->slat = h->slat_buf; return; }
+    if (h->slat_refused && bytes >= h->slat_refused) return;
+    if (h->slat_limit && bytes > h->slat_limit) { h->slat_refused = bytes; return; }     // (the old, smaller plane stays)
+    if (h->slat_buf) (void)hipFree(h->slat_buf);
+    h->slat_buf = nullptr;
+    h->slat_bytes = 0;
+    bool ok = true;
+    if (!h->slat_limit) {
+        size_t free_b = 0, total_b = 0;
+        ok = hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes <= free_b / 2;
+    }
+    void* p = nullptr;
+    if (ok) ok = hipMalloc(&p, bytes) == hipSuccess && p != nullptr;
+    if (!ok) {
+        (void)hipGetLastError();          // the failure is handled here: it must not surface in the next launch's status
+        h->slat_refused = bytes;
+        return;
+    }
+    h->slat_buf = static_cast<float*>(p);
+    h->slat_bytes = bytes;
+    h->slat = h->slat_buf;
 }
 
 // Does this solve keep sin(latitude_field) in a scratch plane (gclm_pass.hip: row_math, SLAT)?  Built-in choice: the
@@ -369,6 +409,7 @@ int gclm_destroy(gclm_handle* h) {
     DeviceGuard guard(h->device);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     if (h->ws) (void)hipFree(h->ws);
+    if (h->slat_buf) (void)hipFree(h->slat_buf);
     if (h->progress_host) (void)hipHostFree(h->progress_host);
     delete h;
     return 0;
@@ -376,7 +417,33 @@ int gclm_destroy(gclm_handle* h) {
 
 const char* gclm_last_error(const gclm_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
-size_t gclm_workspace_bytes(const gclm_handle* h) { return h ? h->ws_bytes : 0; }
+size_t gclm_workspace_bytes(const gclm_handle* h) { return h ? h->ws_bytes + h->slat_bytes : 0; }
+
+size_t gclm_slat_plane_bytes(const gclm_handle* h) { return h ? h->slat_bytes : 0; }
+
+int gclm_set_slat_plane_limit(gclm_handle* h, size_t max_bytes) {
+    if (!h) return -1;
+    h->slat_limit = max_bytes;
+    h->slat_refused = 0;
+    h->sh.active = false;
+    return 0;
+}
+
+int gclm_release_workspace(gclm_handle* h) {
+    if (!h) return -1;
+    DeviceGuard guard(h->device);
+    GCLM_HIP(h, guard.status);
+    h->sh.active = false;
+    if (h->ws) GCLM_HIP(h, hipFree(h->ws));                // (hipFree waits for the device: nothing of this handle is in flight after)
+    h->ws = nullptr;
+    h->ws_bytes = 0;
+    h->ctx = SolveCtx{};
+    h->group_partials = nullptr;
+    if (h->slat_buf) GCLM_HIP(h, hipFree(h->slat_buf));
+    h->slat_buf = h->slat = nullptr;
+    h->slat_bytes = h->slat_refused = 0;
+    return 0;
+}
 
 int gclm_set_sweep_iters(gclm_handle* h, int iters) {
     if (!h) return -1;
@@ -399,6 +466,7 @@ int gclm_set_slat_plane(gclm_handle* h, int mode) {
     if (!h) return -1;
     if (mode < -1 || mode > 1) return fail(h, -3, "gclm_set_slat_plane: mode %d not in {-1, 0, 1}", mode);
     h->slat_plane = mode;
+    h->slat_refused = 0;
     h->sh.active = false;
     return 0;
 }
@@ -414,20 +482,26 @@ int gclm_merge_stop_at(gclm_handle* const* parts, float* const* d_info, const in
     gclm_handle* h0 = parts[0];
     if (n_parts > kMaxMergeParts) return fail(h0, -3, "gclm_merge_stop_at: %d parts, at most %d", n_parts, kMaxMergeParts);
     MergeStopArgs a{};
-    a.n = n_parts;
+    a.n = 0;
     a.num_steps = h0->cfg.num_steps;
     for (int p = 0; p < n_parts; ++p) {
         gclm_handle* h = parts[p];
-        if (!h || !h->ctx.ctrl || (B[p] > 0 && !d_info[p])) return fail(h0, -3, "gclm_merge_stop_at: part %d has not solved anything", p);
+        if (B[p] < 0) return fail(h0, -3, "gclm_merge_stop_at: part %d has a negative size", p);
+        // an EMPTY part holds no image: it adds nothing to the counters and has no row to write (its handle may never have
+        // solved anything, or may hold the counters of an older, non-empty solve -- a B = 0 solve does not touch them)
+        if (B[p] == 0) continue;
+        if (!h || !h->ctx.ctrl || !d_info[p]) return fail(h0, -3, "gclm_merge_stop_at: part %d has not solved anything", p);
         if (h->device != h0->device || h->cfg.num_steps != h0->cfg.num_steps || h->cfg.early_stop)
             return fail(h0, -2, "gclm_merge_stop_at: the parts must share device and num_steps and run with early_stop = 0");
         if (B[p] != h->ctx.B)       // the counters in this handle's workspace are those of its LAST solve
             return fail(h0, -2, "gclm_merge_stop_at: part %d is given as %d images, but the last solve of its handle had %d", p, B[p],
                         h->ctx.B);
-        a.ctrl[p] = h->ctx.ctrl;
-        a.info[p] = d_info[p];
-        a.B[p] = B[p];
+        a.ctrl[a.n] = h->ctx.ctrl;
+        a.info[a.n] = d_info[p];
+        a.B[a.n] = B[p];
+        ++a.n;
     }
+    if (a.n == 0) return 0;
     DeviceGuard guard(h0->device);
     GCLM_HIP(h0, guard.status);
     GCLM_HIP(h0, launch_merge_stop(a, static_cast<hipStream_t>(stream)));
@@ -519,7 +593,8 @@ static int run_solve(gclm_handle* h, const float* d_up, const float* d_lat, cons
     const bool es = h->cfg.early_stop != 0;
     const bool fused_path = use_fused(h, B, geo);
     const bool keep_slat = slat_wanted(h, d_up, d_up_conf, d_lat_conf, geo, fused_path);
-    if (int rc = ensure_workspace(h, B, geo.nchunks, c.n_groups, keep_slat ? (size_t)B * H * W : 0)) return rc;
+    if (int rc = ensure_workspace(h, B, geo.nchunks, c.n_groups)) return rc;
+    ensure_slat(h, keep_slat ? (size_t)B * H * W : 0);
     h->sh.active = false;
     bool slat_ready = false;
 
@@ -654,6 +729,7 @@ int gclm_system(gclm_handle* h, const float* d_up, const float* d_lat, const flo
     c.B = B; c.H = H; c.W = W; c.nchunks = geo.nchunks;
     c.n_groups = 0; c.group_size = 1; c.group_of_frame = nullptr; c.iso_final = 0;
     if (int rc = ensure_workspace(h, B, geo.nchunks, 0)) return rc;
+    h->slat = nullptr;
     h->sh.active = false;
     GCLM_HIP(h, launch_pblock_from_params(c, d_cam, d_grav, as_rpf, c.pb_final, s));
     const SweepArgs a = sweep_args(h, d_up, d_lat, d_up_conf, d_lat_conf, c.pb_final, geo, !as_rpf, 0);
@@ -681,7 +757,8 @@ int gclm_shared_begin(gclm_handle* h, const float* d_up, const float* d_lat, con
     c.B = B_local; c.H = H; c.W = W; c.nchunks = h->sh.geo.nchunks;
     c.n_groups = num_groups; c.group_size = 1; c.group_of_frame = d_group_of_frame; c.iso_final = 0;
     const bool keep_slat = B_local > 0 && slat_wanted(h, d_up, d_up_conf, d_lat_conf, h->sh.geo, false);
-    if (int rc = ensure_workspace(h, Bp, h->sh.geo.nchunks, num_groups, keep_slat ? (size_t)B_local * H * W : 0)) return rc;
+    if (int rc = ensure_workspace(h, Bp, h->sh.geo.nchunks, num_groups)) return rc;
+    ensure_slat(h, keep_slat ? (size_t)B_local * H * W : 0);
     h->sh.slat_ready = false;
     h->sh.up = d_up; h->sh.lat = d_lat; h->sh.upc = d_up_conf; h->sh.latc = d_lat_conf;
     h->sh.cam_io = d_cam_io; h->sh.grav_io = d_grav_io;
@@ -814,6 +891,13 @@ int gclm_pack_fields(const float* d_up_raw, const float* d_up_logconf, const flo
     hipError_t e = launch_pack_fields(d_up_raw, d_up_logconf, d_lat_raw, d_lat_logconf, B, H, W, vec4, d_up, d_up_conf,
                                       d_lat, d_lat_conf, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? 0 : -10;
+}
+
+int gclm_read_probe(const float* const* d_planes, int n_planes, size_t floats, void* stream) {
+    if (!d_planes || n_planes < 1 || n_planes > 8 || floats % 4 != 0) return -3;
+    for (int k = 0; k < n_planes; ++k)
+        if (!d_planes[k] || !is_aligned16(d_planes[k])) return -3;
+    return launch_read_probe(d_planes, n_planes, floats, static_cast<hipStream_t>(stream)) == hipSuccess ? 0 : -10;
 }
 
 int gclm_synth_fields_grouped(int camera_model, uint64_t seed, int64_t first_index, int B, int H, int W,

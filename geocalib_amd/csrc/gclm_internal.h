@@ -186,6 +186,7 @@ hipError_t launch_upsample_multi(const UpsampleMulti& m, int h, int w, int H, in
 hipError_t launch_pack_fields(const float* up_raw, const float* up_lc, const float* lat_raw, const float* lat_lc,
                               int B, int H, int W, bool vec4, float* up, float* upc, float* lat, float* latc,
                               hipStream_t s);
+hipError_t launch_read_probe(const float* const* planes, int n, size_t floats, hipStream_t s);
 hipError_t launch_synth(int camera_model, uint64_t seed, int64_t first_index, int B, int H, int W,
                         float sigma, int group_size, int run, int run_stride, float* up, float* lat, float* upc, float* latc, float* gt_cam,
                         float* gt_grav, hipStream_t s);

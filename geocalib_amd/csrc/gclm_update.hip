@@ -1196,6 +1196,33 @@ hipError_t launch_pack_fields(const float* up_raw, const float* up_lc, const flo
     return hipGetLastError();
 }
 
+// gclm_read_probe (include/gclm.h): the sweep's load -- non-temporal, 16 B per lane, consecutive lanes on consecutive
+// addresses -- over up to 8 planes, four loads per plane in flight per thread, nothing else: the memory-system ceiling of the
+// sweep's access pattern on the caller's own buffers.
+struct ReadProbeArgs { const float* p[8]; int n; };
+__global__ __launch_bounds__(256) void read_probe_kernel(ReadProbeArgs a, size_t units, float* sink) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    constexpr int kUnroll = 4;
+    const size_t base = (size_t)blockIdx.x * (256 * kUnroll) + threadIdx.x;
+    v4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+        const size_t i = base + (size_t)u * 256;
+        if (i < units)
+            for (int k = 0; k < a.n; ++k) acc += __builtin_nontemporal_load(reinterpret_cast<const v4*>(a.p[k]) + i);
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 1.2345e30f && sink) sink[0] = acc.x;      // never: keeps the loads alive
+}
+hipError_t launch_read_probe(const float* const* planes, int n, size_t floats, hipStream_t s) {
+    ReadProbeArgs a{};
+    a.n = n;
+    for (int k = 0; k < n; ++k) a.p[k] = planes[k];
+    const size_t units = floats / 4;
+    if (units == 0) return hipSuccess;
+    hipLaunchKernelGGL(read_probe_kernel, dim3((unsigned)((units + 1023) / 1024)), dim3(256), 0, s, a, units, (float*)nullptr);
+    return hipGetLastError();
+}
+
 hipError_t launch_synth(int camera_model, uint64_t seed, int64_t first_index, int B, int H, int W, float sigma,
                         int group_size, int run, int run_stride, float* up, float* lat, float* upc, float* latc, float* gt_cam, float* gt_grav,
                         hipStream_t s) {

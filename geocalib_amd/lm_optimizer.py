@@ -444,7 +444,7 @@ class LMOptimizer(nn.Module):
         grav = torch.empty((B, 3), dtype=torch.float32, device=device)
         info = torch.empty((B, _lib.INFO_STRIDE), dtype=torch.float32, device=device)
         P = self._ptr           # (the library switches to the handle's device itself: no torch.cuda.device() context)
-        n_over = self._overlap_parts(B, H, W, h, all(t is None or t.data_ptr() % 16 == 0 for t in (up, lat, upc, latc)))
+        n_over = self._overlap_parts(B, H, W, h, lambda: all(t is None or t.data_ptr() % 16 == 0 for t in (up, lat, upc, latc)))
         if n_over > 1:
             self._calibrate_overlapped(n_over, device, (up, lat, upc, latc), (B, H, W), scales, (pf, pg, pd), nd, (cam, grav, info))
         else:
@@ -466,33 +466,50 @@ class LMOptimizer(nn.Module):
     #                   inside the regime where the cut does not depend on the batch size (`_OVERLAP_AUTO_PIXELS` pixels per
     #                   part: 410 images of 640x480), i.e. only where the result is the single call's bit for bit; 1 otherwise.
     #   1: never (measurement rigs that time single launches: overlapping launches have no separable durations).
-    #   n > 1: n parts wherever every part keeps `_OVERLAP_MIN_IMAGES` images.
+    #   n > 1: n parts wherever every part keeps `_OVERLAP_MIN_IMAGES` images (where the library would cut a part differently
+    #          from the whole batch -- gclm_plan_cut -- the split still happens and a warning says, once, that the results
+    #          then equal the single call's only up to summation order).
     # Ignored where it does not apply: early_stop (one decision over the whole batch), shared intrinsics.
     overlap_streams = None
     _OVERLAP_MIN_IMAGES = 256
     _OVERLAP_AUTO_PIXELS = 3 * 2048 * 20480      # 3 x (2048 workgroups x 20 480 pixels per workgroup at 20 iterations)
 
-    def _overlap_parts(self, B: int, H: int = 480, W: int = 640, handle=None, aligned16: bool = True) -> int:
+    def _overlap_parts(self, B: int, H: int = 480, W: int = 640, handle=None, aligned16=True) -> int:
+        """How many side-stream parts this batch is solved as.  `aligned16`: a bool, or a callable evaluated only once the
+        cheap early-outs (early stop, shared intrinsics, batch size) have passed."""
         if self.conf.early_stop or self.shared_intrinsics:
             return 1
-        if self.overlap_streams is None:
+        auto = self.overlap_streams is None
+        if auto:
             if not (B // 2 >= self._OVERLAP_MIN_IMAGES and (B // 2) * H * W >= self._OVERLAP_AUTO_PIXELS):
                 return 1
-            if handle is None:
-                return 2
-            # the promise of the automatic mode is the single call's bits: the LIBRARY says how it would cut the whole batch
-            # and each part (gclm_plan_cut; the side-stream handles share this handle's configuration) -- no mirrored rule
-            cuts = set()
-            for n in (B, B // 2, B - B // 2):
-                rows = _lib.C.c_int(0)
-                _lib.check(_lib.load().gclm_plan_cut(handle.ptr, n, H, W, int(aligned16), _lib.C.byref(rows), None), handle.ptr,
-                           "gclm_plan_cut")
-                cuts.add(rows.value)
-            return 2 if len(cuts) == 1 else 1
-        n = int(self.overlap_streams)
-        if n <= 1:
+            n = 2
+        else:
+            n = int(self.overlap_streams)
+            n = max(1, min(n, B // self._OVERLAP_MIN_IMAGES)) if n > 1 else 1
+        if n <= 1 or handle is None:
+            return n
+        # the single call's bits are promised only where every part is cut like the whole batch: the LIBRARY says how it would
+        # cut each (gclm_plan_cut; the side-stream handles share this handle's configuration) -- no mirrored rule
+        if callable(aligned16):
+            aligned16 = aligned16()
+        cuts = set()
+        for size in {B} | {B * (i + 1) // n - B * i // n for i in range(n)}:
+            rows = _lib.C.c_int(0)
+            _lib.check(_lib.load().gclm_plan_cut(handle.ptr, size, H, W, int(aligned16), _lib.C.byref(rows), None), handle.ptr,
+                       "gclm_plan_cut")
+            cuts.add(rows.value)
+        if len(cuts) == 1:
+            return n
+        if auto:
             return 1
-        return max(1, min(n, B // self._OVERLAP_MIN_IMAGES))
+        if not self.__dict__.get("_warned_overlap_cut"):
+            # an explicit request is honoured, and said once: the parts' partial records are summed in another order
+            self.__dict__["_warned_overlap_cut"] = True
+            logger.warning("geocalib_amd.LMOptimizer.overlap_streams=%d: parts of a batch of %d images of %dx%d are not cut like "
+                           "the whole batch; results equal the single call's up to float32 summation order, not bit for bit "
+                           "(overlap_streams=None only splits where they are bit-identical)", n, B, W, H)
+        return n
 
     def _calibrate_overlapped(self, n, device, fields, shape, scales, priors, nd, outs):
         B, H, W = shape

@@ -9,9 +9,10 @@
  * `d_*` are DEVICE pointers owned by the caller (torch-ROCm tensors); `stream` is a hipStream_t
  * passed as void*.  Calls are asynchronous on `stream` and never synchronise the device -- with ONE exception: a
  * handle's workspace is allocated by the first solve and GROWN by the first solve of a larger shape than any before
- * (batch size, chunks per image, groups, the sin(latitude) scratch plane): that call runs hipFree + hipMalloc, which
- * synchronises the device once.  Every later call of that shape or a smaller one finds the workspace in place: no
- * allocation and no synchronisation after warm-up (gclm_workspace_bytes reports its size).
+ * (batch size, chunks per image, groups; the sin(latitude) scratch plane, an allocation of its own -- see
+ * gclm_set_slat_plane): that call runs hipFree + hipMalloc, which synchronises the device once.  Every later call of that
+ * shape or a smaller one finds the workspace in place: no allocation and no synchronisation after warm-up
+ * (gclm_workspace_bytes reports its size, gclm_release_workspace gives it back).
  * Return value: 0 = ok, negative = error (message via gclm_last_error).  No C++ exception crosses
  * this boundary.  A handle is not thread-safe and owns the whole solve workspace: one handle per (device, stream).
  * Every entry point runs on the handle's device and restores the caller's current HIP device before it returns.
@@ -39,9 +40,11 @@ extern "C" {
  * struct_size / abi_version / device moved into gclm_config, gclm_create lost its third argument, new entry points
  * gclm_set_sweep_iters, gclm_set_fused_steps, gclm_set_paced_launches, gclm_set_stop_comm, gclm_comm_all_reduce_sum_i32,
  * gclm_abi_config_size; 400 = round 4: gclm_comm_versions, gclm_merge_stop_at and gclm_upsample_fields_multi added, the NULL-handle error strings became thread-local, an
- * empty batch (B = 0, NULL fields) is accepted by gclm_solve / gclm_calibrate; 500 = round 5: gclm_set_slat_plane and gclm_plan_cut added).  gclm_create refuses a gclm_config whose first two fields do not
+ * empty batch (B = 0, NULL fields) is accepted by gclm_solve / gclm_calibrate; 500 = round 5: gclm_set_slat_plane and gclm_plan_cut added;
+ * 600 = round 6: gclm_set_slat_plane_limit, gclm_slat_plane_bytes, gclm_release_workspace and gclm_read_probe added, the
+ * scratch plane became an optional allocation of its own, gclm_merge_stop_at skips empty parts).  gclm_create refuses a gclm_config whose first two fields do not
  * carry the library's own sizeof(gclm_config) and GCLM_VERSION, with a message naming both sides. */
-#define GCLM_VERSION 500
+#define GCLM_VERSION 600
 
 /* camera_models of geocalib/camera.py:945-950 */
 enum gclm_camera_model {
@@ -133,8 +136,14 @@ int gclm_destroy(gclm_handle* h);
  * (thread-local storage: two threads creating handles do not see each other's message). */
 const char* gclm_last_error(const gclm_handle* h);
 
-/* Bytes of device scratch the handle holds (grows on demand in gclm_solve, never per call after warm-up). */
+/* Bytes of device scratch the handle holds (grows on demand in gclm_solve, never per call after warm-up): the core
+ * workspace (per-image states, parameter blocks, partial records: ~3 KB per image) plus the sin(latitude) scratch plane
+ * where one is held (gclm_slat_plane_bytes: H x W x 4 bytes per image). */
 size_t gclm_workspace_bytes(const gclm_handle* h);
+size_t gclm_slat_plane_bytes(const gclm_handle* h);
+/* Give the handle's device memory back (hipFree: waits for the device, so nothing of the handle is in flight after).  The
+ * handle stays valid; its next solve allocates again.  For serving loops that have seen a rare huge batch. */
+int gclm_release_workspace(gclm_handle* h);
 
 /*
  * LMOptimizer.optimize (lm_optimizer.py:551-644) for B images of H x W pixels: all LM steps,
@@ -210,6 +219,10 @@ int gclm_pack_fields(const float* d_up_raw, const float* d_up_logconf, const flo
  * The step AFTER the path: GeoCalib._post_process (geocalib/extractor.py:51-69) resizes the fields and confidences
  * back to the input resolution with F.interpolate(mode="bilinear", align_corners=False).  `planes` = number of
  * contiguous (h, w) planes in d_src (e.g. B*2 for the up field); d_dst holds planes x (H, W).
+ * The sources must be FINITE: the vector path reads a window of 4 or 5 consecutive source floats per lane and multiplies
+ * the ones an output does not tap by an exact 0, so a NaN / Inf source pixel reaches up to four output pixels beyond the
+ * ones F.interpolate would make non-finite (which itself turns a zero-weight non-finite tap into NaN).  The CNN-head
+ * outputs this entry point exists for (unit up vectors, asin(tanh) latitudes, sigmoid confidences) are always finite.
  */
 int gclm_upsample_fields(const float* d_src, int planes, int h, int w, int H, int W, float* d_dst, void* stream);
 /* ... and the same for up to 8 tensors of (h, w) planes in ONE launch (the four tensors _post_process resizes: a
@@ -284,6 +297,16 @@ int gclm_synth_fields_grouped(int camera_model, uint64_t seed, int64_t first_ind
                               float* d_gt_grav, void* stream);
 
 /*
+ * Measurement helper (bench.py: roofline.read_ceiling_frac; no reference counterpart): ONE launch that streams n_planes
+ * (<= 8) device planes of `floats` floats each (16-byte aligned, floats % 4 == 0) with the sweep's own load -- non-temporal,
+ * 16 bytes per lane, consecutive lanes on consecutive addresses, four loads per plane in flight per thread -- and no
+ * arithmetic beyond the sum that keeps the loads alive.  Its duration is what THESE buffers can stream on THIS box: the
+ * memory-system ceiling of the sweep's access pattern for the allocation a measurement was taken on.  d_planes is a HOST
+ * array of device pointers.  Asynchronous on `stream`; the caller times it (events on that stream).
+ */
+int gclm_read_probe(const float* const* d_planes, int n_planes, size_t floats, void* stream);
+
+/*
  * Multi-GPU collectives over RCCL / xGMI, one process per GPU (no reference counterpart: the
  * reference's LM is single-process).  gclm_comm_unique_id is called on rank 0 only and its 128 bytes are handed to
  * the other ranks by the caller.  Both collectives are asynchronous on `stream`.
@@ -329,7 +352,8 @@ int gclm_set_stop_comm(gclm_handle* h, gclm_comm* c);
  * EVERY image's cost was close" (lm_optimizer.py:619-620) is one number for the whole batch.  It re-derives stop_at from
  * the SUM of the parts' per-step counters and writes it into every row of every part's info.  At most 8 parts, same
  * device / num_steps.  The counters live in each handle's workspace and are those of the handle's LAST solve, so:
- *   - B[p] MUST be the batch size of part p's last gclm_solve / gclm_calibrate (checked: -2 otherwise);
+ *   - B[p] MUST be the batch size of part p's last gclm_solve / gclm_calibrate (checked: -2 otherwise); a part with
+ *     B[p] == 0 is skipped (it holds no image: its handle need not have solved anything);
  *   - `stream` MUST be ordered after every part's solve (events / stream waits are the caller's business), and no part
  *     handle may start another solve before the merge kernel has run (it would overwrite the counters being summed). */
 int gclm_merge_stop_at(gclm_handle* const* parts, float* const* d_info, const int* B, int n_parts, void* stream);
@@ -355,8 +379,20 @@ int gclm_plan_cut(const gclm_handle* h, int B, int H, int W, int aligned16, int*
  * (float32 radians) does not change.
  * mode -1 (default): the library decides (simple_radial / radial / simple_divisional with all five planes on the
  * 16-byte-aligned path, at least one LM step, not the one-launch-per-step path; never pinhole, which is memory-bound);
- * 0: never (saves B x H x W x 4 bytes of workspace); 1: wherever the sweep has the instantiation (also pinhole). */
+ * 0: never (saves B x H x W x 4 bytes of workspace); 1: wherever the sweep has the instantiation (also pinhole).
+ *
+ * The plane is OPTIONAL in every mode.  It is an allocation of its own, of exactly B x H x W x 4 bytes (no headroom; 1.26 GB
+ * for 1024 images of 640x480, against 3 MB for the rest of the workspace), and a solve that cannot have it runs the sweeps
+ * that compute sin(latitude) themselves -- the same bits, a few per cent slower -- instead of failing: when hipMalloc
+ * fails, or when the plane would exceed the limit.  gclm_set_slat_plane_limit: max_bytes = 0 (default) = the built-in rule,
+ * at most HALF of the device memory that is free when the plane is (re)allocated; otherwise a plane is only (re)allocated
+ * while B x H x W x 4 <= max_bytes (1 = in effect never; a plane the handle already holds keeps serving the solves it is
+ * large enough for -- gclm_release_workspace drops it).  A refused size is remembered until the limit or the mode is set again,
+ * so a serving loop does not pay a failing allocation per call.  Only the core workspace failing to allocate is an error
+ * (-10).  A batch solved as n parts by n handles (LMOptimizer.overlap_streams) holds n planes of B / n images each: one
+ * plane's worth in total. */
 int gclm_set_slat_plane(gclm_handle* h, int mode);
+int gclm_set_slat_plane_limit(gclm_handle* h, size_t max_bytes);
 
 /* Small batches (the interactive single-image calibration of the reference's demo, interactive_demo.py:403) run ONE
  * launch per LM step: the per-image update of step k-1 is done in the prologue of every workgroup of sweep k

@@ -44,8 +44,14 @@ def test_no_sweep_kernel_carries_an_lds_array_or_scratch_it_was_not_given(tmp_pa
     assert all(v["lds"] <= 2816 for v in fused.values()), {n: v for n, v in fused.items() if v["lds"] > 2816}
     # scratch: none, except general-focal (LOGF = 0: a non-default conf, or the ONE final sweep of a solve with fx != fy)
     # instantiations held to 168 VGPRs: two of simple_divisional (8 / 16 B) and radial's scratch-plane reader (8 B)
-    spilling = {n: v["scratch"] for n, v in {**sweeps, **fused}.items() if v["scratch"]}
-    assert all(("ILi3E" in n or "ILi2E" in n) and "Lb0ELi4E" in n and s <= 16 for n, s in spilling.items()) and len(spilling) <= 3, spilling
+    # -- pinned by their exact template arguments <MODEL, HAS_UP, HAS_UPC, HAS_LATC, LOGF = 0, VEC = 4, SLAT>, with the bytes each
+    # may spill (a substring match plus a count would let any other instantiation start spilling unnoticed)
+    spilling = {re.search(r"sweep_kernelI(\w+?)EEv|fused_step_kernelI(\w+?)EEv", n).group(0): v["scratch"]
+                for n, v in {**sweeps, **fused}.items() if v["scratch"]}
+    allowed = {"sweep_kernelILi3ELb1ELb0ELb1ELb0ELi4ELi0EEEv": 8,      # simple_divisional, no up confidence, general focal
+               "sweep_kernelILi3ELb1ELb1ELb1ELb0ELi4ELi0EEEv": 16,     # simple_divisional, five planes, general focal
+               "sweep_kernelILi2ELb1ELb1ELb1ELb0ELi4ELi2EEEv": 8}      # radial, scratch-plane reader, general focal
+    assert all(spilling[n] <= allowed.get(n, 0) for n in spilling), (spilling, allowed)
     # the BASELINE instantiations keep their occupancy: pinhole 80 VGPRs (6 waves / SIMD), simple_radial <= 128 (4 waves)
     main = {m: next(v for n, v in sweeps.items() if f"sweep_kernelILi{m}ELb1ELb1ELb1ELb1ELi4ELi0E" in n) for m in range(4)}
     assert main[0]["vgpr"] <= 80 and main[1]["vgpr"] <= 128 and main[2]["vgpr"] <= 168 and main[3]["vgpr"] <= 168, main
