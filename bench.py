@@ -21,8 +21,15 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
                 with the CPU oracle (oracle/lm_oracle.c, a port) beside it as `port`.  Where it does not (the GPU box):
                 the port is the baseline (kind "port", reference_on_this_box false) and `reference_torch` carries the
                 reference's timing from the build container (profiles/cpu_reference_torch.json, hardware named).
+  check:        the line's own correctness record.  `vs_oracle`: the HIP results of the first images of rank 0's TIMED batch
+                against the CPU oracle's solve of the very same fields (oracle/lm_oracle.c, the restatement of the reference
+                that tests/test_oracle.py pins to reference-generated goldens; the solve the cpu_baseline leg times anyway):
+                max focal rel / max gravity abs / max final-cost rel distance next to north_star's 1e-4 gate.  The
+                ground-truth errors beside it are the noise floor of the synthetic data, not a parity figure.
   secondary:    N=1 default run only: BASELINE configs[3] (simple_radial, B=1024) and configs[4]'s shape (shared intrinsics,
-                64 groups x 16 frames) at 5 steps after 2 warm-ups each, same event-based sweep timing and ground-truth check.
+                64 groups x 16 frames) at 5 steps after 2 warm-ups each, same event-based sweep timing, ground-truth check and
+                `check.vs_oracle` (64 images each); configs[3] also carries `slat_off`: the same solves on the same allocation
+                with the sin(latitude) scratch plane switched off (gclm_set_slat_plane(h, 0)) -- the plane's effect on THIS box.
   overlap:      N=1, independent intrinsics: the same batch solved as two halves on two side streams
                 (LMOptimizer.overlap_streams = 2, the library's default for large batches); `value` stays the one-stream run.
 The timed region (exactly --steps steps between barrier + synchronize) is run --repeats times; `value` and
@@ -30,6 +37,11 @@ The timed region (exactly --steps steps between barrier + synchronize) is run --
 `value`, `ms_per_step` and `roofline` are measured on every rank's FIRST allocation of its input fields; at N = 1
 `placement.best_of_n` carries, beside them, the same measurement on the fastest-streaming of --placement-tries allocations
 (a serving loop may choose where its persistent field buffers live; the line of record does not).
+`roofline.read_ceiling_frac`: what THIS allocation streams on THIS box with the sweep's own load and no arithmetic
+(gclm_read_probe over the five timed planes, 5 launches), as a fraction of the 8 TB/s peak; `frac_of_read_ceiling` = frac / that.
+For N > 1 the line also carries `multi_gpu.parity`: rank 0 re-generates the shard of ANOTHER rank from (seed, first index),
+solves it alone and compares the gathered rows of that rank bit for bit (image / group sharding); for the frame split it solves
+whole groups alone and records the distance of the split result (gate 1e-4).
 For N > 1 the line also carries `multi_gpu`: ranks_seen (from the communicator), per_rank_ms (every rank's own
 median step time) and collective_ms (device time inside the collectives per step, max over ranks); `roofline.per_rank_frac`
 lists every rank's own sweep fraction (its own HIP events) and `roofline.frac` is their MINIMUM.
@@ -95,7 +107,72 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(args, n_images, host_data):
+ORACLE_GATE = 1e-4     # north_star: "matching reference focal/gravity to <1e-4 rel"
+
+
+def vs_oracle(hip, ref, what):
+    """Distance of the HIP results from the CPU oracle's on the same images: `hip` / `ref` = dicts of numpy arrays with
+    camera (n,8), gravity (n,3), final_cost (n,)."""
+    import numpy as np
+    n = ref["camera"].shape[0]
+    f = float(np.abs(hip["camera"][:n, 2:4] / ref["camera"][:, 2:4] - 1).max())
+    g = float(np.abs(hip["gravity"][:n] - ref["gravity"]).max())
+    c = float(np.abs(hip["final_cost"][:n] / ref["final_cost"] - 1).max())
+    d = [x for x in (f, g, c)]
+    return {"images": int(n), "max_focal_rel": f, "max_gravity_abs": g, "max_final_cost_rel": c, "gate": ORACLE_GATE,
+            "within_gate": bool(all(x == x and x <= ORACLE_GATE for x in d)),        # (x == x: a NaN is not within any gate)
+            "against": "oracle/lm_oracle.c (float32), " + what}
+
+
+def oracle_solve(model, lm_steps, data, group, cores):
+    """The checker's answer on `data` (numpy, float32): oracle/lm_oracle.c at float32, independent images, or -- `group` > 0 --
+    shared-intrinsics groups of `group` frames, ONE group per call as the reference solves them (lm_optimizer.py:350-383)."""
+    import numpy as np
+    from oracle import lm_oracle
+    conf = {"camera_model": model, "num_steps": lm_steps, "early_stop": False}
+    n = next(iter(data.values())).shape[0]
+    if group:
+        outs = [lm_oracle.solve({k: v[lo:lo + group] for k, v in data.items()}, {**conf, "shared_intrinsics": True}, precision="f32",
+                                num_threads=cores) for lo in range(0, n, group)]
+    else:
+        outs = [lm_oracle.solve(data, conf, precision="f32", num_threads=cores)]
+    return {k: np.concatenate([o[k] for o in outs]) for k in ("camera", "gravity", "final_cost")}
+
+
+def hip_rows(out, n):
+    """camera / gravity / final_cost of the first n images of a result dict, on the host"""
+    return {"camera": out["camera"]._data[:n].cpu().numpy(), "gravity": out["gravity"]._data[:n].cpu().numpy(),
+            "final_cost": out["final_cost"][:n].cpu().numpy()}
+
+
+def read_ceiling(lib, data, dev, launches=5):
+    """What the five planes of `data` stream on this box with the sweep's own load and nothing else (gclm_read_probe): mean
+    of `launches` launches after two warm-ups, HIP events on the launch stream.  None when the fields are not the five
+    16-byte-aligned planes."""
+    if not all(k in data for k in ("up_field", "latitude_field", "up_confidence", "latitude_confidence")):
+        return None
+    n = data["latitude_field"].numel()
+    flat = data["up_field"].reshape(-1)
+    planes = [flat[:n], flat[n:], data["latitude_field"].reshape(-1), data["up_confidence"].reshape(-1),
+              data["latitude_confidence"].reshape(-1)]
+    if n == 0 or n % 4 or any(q.numel() != n or q.data_ptr() % 16 for q in planes):
+        return None
+    arr = (C.c_void_p * 5)(*[q.data_ptr() for q in planes])
+    stream = torch.cuda.current_stream(dev)
+    for _ in range(2):
+        lib.gclm_read_probe(arr, 5, n, stream.cuda_stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(launches):
+        if lib.gclm_read_probe(arr, 5, n, stream.cuda_stream) != 0:
+            return None
+    e1.record(stream)
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / launches
+    return {"ms": ms, "frac": 5 * n * 4 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "launches": launches}
+
+
+def cpu_baseline(args, n_images, host_data, keep=None):
     """The CPU baseline on a bounded sample: the FIRST n images of the very batch rank 0's GPU was timed on, already copied
     to the host (numpy, float32).  Runs on rank 0 after the timed regions and the last barrier, at every N (the other
     ranks' processes are idle by then: the sample gets the box's granted cores to itself).
@@ -106,7 +183,10 @@ def cpu_baseline(args, n_images, host_data):
     (kind "reference", measured_on "this box") with the port beside it.
 
     --shared-group G: the sample is cut into groups of G frames, each solved as the reference solves a shared-intrinsics
-    batch (ONE group per call, lm_optimizer.py:350-383), one call after the other."""
+    batch (ONE group per call, lm_optimizer.py:350-383), one call after the other.
+
+    `keep` (a dict): receives the oracle's camera / gravity / final_cost of the sample -- the checker's answer on the timed
+    fields, which the caller compares the HIP results with (`check.vs_oracle`)."""
     from oracle import lm_oracle, ref_import
     cores = lm_oracle.effective_cpus()        # what the cgroup grants, not what the box has
     lm_oracle.build()
@@ -114,15 +194,11 @@ def cpu_baseline(args, n_images, host_data):
     if group:
         n_images = max(group, n_images // group * group)
     data = {k: v[:n_images] for k, v in host_data.items()}
-    conf = {"camera_model": args.camera_model, "num_steps": args.lm_steps, "early_stop": False}
     t0 = time.perf_counter()
-    if group:
-        for lo in range(0, n_images, group):
-            lm_oracle.solve({k: v[lo:lo + group] for k, v in data.items()}, {**conf, "shared_intrinsics": True}, precision="f32",
-                            num_threads=cores)
-    else:
-        lm_oracle.solve(data, conf, precision="f32", num_threads=cores)
+    solved = oracle_solve(args.camera_model, args.lm_steps, data, group, cores)
     dt = time.perf_counter() - t0
+    if keep is not None:
+        keep.update(solved)
     port = {"value": round(n_images / dt, 3), "unit": "images/sec" if not group else "frames/sec",
             "cores": min(cores, group or n_images), "kind": "port",
             "sample": f"the first {n_images} images of rank 0's timed batch ({args.width}x{args.height}), {args.lm_steps} LM iters, "
@@ -188,33 +264,41 @@ def reference_torch(args):
                       f"{m['seconds']} s", "source": "profiles/cpu_reference_torch.json"}
 
 
-def quick_case(lib, LMOptimizer, synth_fields, dev, model, B, H, W, lm_steps, seed, group, steps=5, warmup=2):
+def quick_case(lib, LMOptimizer, synth_fields, dev, model, B, H, W, lm_steps, seed, group, steps=5, warmup=2, oracle_images=64,
+               slat_control=False):
     """One secondary record: `steps` solves after `warmup`, first allocation, one stream; sweep launches timed with the
-    library's HIP events, result checked against the synthetic ground truth like the headline."""
+    library's HIP events, result checked against the synthetic ground truth like the headline and -- the first
+    `oracle_images` images -- against the CPU oracle's solve of the same fields.  `slat_control`: the same measurement again
+    with the sin(latitude) scratch plane off, then on again (same allocation, same process: A / B / A)."""
     conf = {"camera_model": model, "num_steps": lm_steps, "early_stop": False}
     if group:
         conf.update(shared_intrinsics=True, group_size=group)
     opt = LMOptimizer(conf).eval()
     opt.overlap_streams = 1
     data, gt_cam, gt_grav = synth_fields(model, B, H, W, dev, seed=seed, group_size=group or 1)
-    for _ in range(warmup):
-        out = opt(data)
-    torch.cuda.synchronize()
     h = opt._handle(dev)
-    lib.gclm_set_timing(h.ptr, 1)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        out = opt(data)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    n, ms = C.c_int(0), C.c_float(0)
-    lib.gclm_last_pass_timing(h.ptr, C.byref(n), C.byref(ms))
-    lib.gclm_set_timing(h.ptr, 0)
+    bytes_per_launch = B * H * W * PLANES * 4
+
+    def measure():
+        for _ in range(warmup):
+            opt(data)
+        torch.cuda.synchronize()
+        lib.gclm_set_timing(h.ptr, 1)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = opt(data)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n, ms = C.c_int(0), C.c_float(0)
+        lib.gclm_last_pass_timing(h.ptr, C.byref(n), C.byref(ms))
+        lib.gclm_set_timing(h.ptr, 0)
+        avg = ms.value / max(n.value, 1)
+        return res, dt, avg, n.value
+
+    out, dt, avg_ms, n_timed = measure()
     f_err = (out["camera"]._data[:, 3] / gt_cam[:, 3] - 1).abs().median().item()
     g_err = (out["gravity"]._data - gt_grav).abs().max(1).values.median().item()
     assert f_err < 5e-3 and g_err < 5e-3, (model, group, f_err, g_err)
-    avg_ms = ms.value / max(n.value, 1)
-    bytes_per_launch = B * H * W * PLANES * 4
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
     value = B * steps / dt
     rec = {"workload": (f"BASELINE configs[3]: batch={B}, {model}" if not group else
@@ -223,10 +307,41 @@ def quick_case(lib, LMOptimizer, synth_fields, dev, model, B, H, W, lm_steps, se
            "value": round(value, 1), "unit": "images/sec" if not group else "frames/sec", "steps": steps, "warmup": warmup,
            "ms_per_step": round(dt / steps * 1e3, 4),
            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 4), "avg_launch_ms": round(avg_ms, 4), "launches_timed": n.value,
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "avg_launch_ms": round(avg_ms, 4), "launches_timed": n_timed,
                         "whole_job_frac": round(value * (lm_steps + 1) * H * W * PLANES * 4 / 1e9 / HBM_PEAK_GBS, 4)},
            "check": {"median_focal_rel_err_vs_gt": f_err, "median_gravity_abs_err_vs_gt": g_err},
+           "workspace_bytes": int(lib.gclm_workspace_bytes(h.ptr)), "slat_plane_bytes": int(lib.gclm_slat_plane_bytes(h.ptr)),
            "placement": "first allocation (no choice among allocations)"}
+    rc = read_ceiling(lib, data, dev)
+    if rc is not None:
+        rec["roofline"].update(read_ceiling_frac=round(rc["frac"], 4), frac_of_read_ceiling=round(achieved / HBM_PEAK_GBS / rc["frac"], 4))
+    if slat_control:
+        on_raw = [t.clone() for t in opt._last_raw]
+        lib.gclm_set_slat_plane(h.ptr, 0)
+        _, dt0, avg0, n0 = measure()
+        same = all(bool(((a == b) | (a.isnan() & b.isnan())).all()) for a, b in zip(on_raw, opt._last_raw))
+        lib.gclm_set_slat_plane(h.ptr, -1)
+        _, dt2, avg2, _ = measure()
+        rec["slat_off"] = {"value": round(B * steps / dt0, 1), "ms_per_step": round(dt0 / steps * 1e3, 4),
+                           "frac": round(bytes_per_launch / (avg0 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(avg0, 4),
+                           "launches_timed": n0, "bit_identical": bool(same),
+                           "on_again": {"value": round(B * steps / dt2, 1), "ms_per_step": round(dt2 / steps * 1e3, 4),
+                                        "frac": round(bytes_per_launch / (avg2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                           "what": "the same solves on the same allocation with gclm_set_slat_plane(h, 0): every sweep evaluates "
+                                   "sin(latitude) per pixel instead of loading the library's scratch plane; then the default "
+                                   "again (`on_again`).  `value` / `roofline` above are the default (plane on)"}
+    if oracle_images:
+        try:
+            from oracle.lm_oracle import effective_cpus
+            n = min(B, oracle_images)
+            if group:
+                n = max(group, n // group * group)
+            host = {k: v[:n].cpu().numpy() for k, v in data.items()}
+            rec["check"]["vs_oracle"] = vs_oracle(hip_rows(out, n), oracle_solve(model, lm_steps, host, group, effective_cpus()),
+                                                  f"the first {n} images of this case's timed batch" +
+                                                  (f" as {n // group} shared-intrinsics groups of {group}" if group else ""))
+        except Exception as e:          # the checker must never take the product measurement down
+            rec["check"]["vs_oracle"] = {"error": repr(e)}
     del data, out
     torch.cuda.empty_cache()
     return rec
@@ -454,6 +569,11 @@ def main():
         _lib.check(lib.gclm_last_pass_timing(handle.ptr, C.byref(n), C.byref(ms)), handle.ptr, "timing")
         sweep_ms, sweep_n = ms.value, n.value
     algo_bytes_per_launch = B * H * W * PLANES * 4
+    if not args.no_timing:
+        lib.gclm_set_timing(handle.ptr, 0)
+    # the pure-read ceiling of THIS rank's allocation, right after the timed regions (same buffers, same clocks)
+    own_rc = read_ceiling(lib, data, dev)
+    own_rc_frac = own_rc["frac"] if own_rc is not None else 0.0
 
     def algo_frac(avg_launch_ms):
         """algorithmic bytes of one sweep launch / its duration, as a fraction of the HBM peak"""
@@ -461,18 +581,20 @@ def main():
 
     own_sweep_ms = sweep_ms / sweep_n if sweep_n else 0.0
     ranks_seen, per_rank_ms, coll_ms_max, per_rank_sweep_ms = world, [own / args.steps * 1e3], coll_ms, [own_sweep_ms]
+    per_rank_rc = [own_rc_frac]
     if distributed:
         tdev = dev if args.backend == "nccl" else "cpu"
         t = torch.tensor(regions, device=tdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)           # every region: MAX over ranks, then the median region
         regions = t.tolist()
         ranks_seen = dist.get_world_size()
-        mine = torch.tensor([own / args.steps * 1e3, coll_ms, own_sweep_ms], device=tdev, dtype=torch.float64)
+        mine = torch.tensor([own / args.steps * 1e3, coll_ms, own_sweep_ms, own_rc_frac], device=tdev, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(ranks_seen)]
         dist.all_gather(allr, mine)
         per_rank_ms = [round(x[0].item(), 4) for x in allr]
         coll_ms_max = max(x[1].item() for x in allr)
         per_rank_sweep_ms = [x[2].item() for x in allr]     # every rank's own mean sweep launch (its own HIP events)
+        per_rank_rc = [x[3].item() for x in allr]           # ... and its own allocation's pure-read ceiling
     elapsed = sorted(regions)[len(regions) // 2]
 
     # sanity: the solve must have recovered the synthetic ground truth (a fast wrong answer is no answer)
@@ -498,7 +620,6 @@ def main():
     extras = {}
     solo = world == 1 and not distributed and gs == 0 and not overlapped
     if solo:
-        lib.gclm_set_timing(handle.ptr, 0)
         if placement["tries"] > 1:
             # beside the line of record: what a serving loop that CHOOSES among allocations of its persistent field buffers
             # gets on this box (geocalib_amd.fields.fastest_placement) -- the first allocation is candidate 0
@@ -537,20 +658,69 @@ def main():
             extras["overlap"] = {"streams": 2, "value": round(v2, 1), "ms_per_step": round(sec / args.steps * 1e3, 4),
                                  "bit_identical": bool(same),
                                  "whole_job_frac": round(v2 * (args.lm_steps + 1) * H * W * PLANES * 4 / 1e9 / HBM_PEAK_GBS, 4)}
-    host_sample = None
+    host_sample = hip_sample = None
     if rank == 0 and args.cpu_sample != 0:
         from oracle.lm_oracle import effective_cpus
         n_cpu = min(B, args.cpu_sample if args.cpu_sample > 0 else max(8, 16 * effective_cpus()))   # ~7-10 s of CPU work
         if gs:
             n_cpu = min(B, max(gs, n_cpu // gs * gs))      # whole groups of the sample (any gs frames: the work is the same)
         host_sample = {k: v[:n_cpu].cpu().numpy() for k, v in data.items()}
+        # rank 0's rows come first in a gathered result; the oracle's solve of the sample is the same sub-problem as the HIP
+        # solve wherever rank 0 holds whole groups (always for independent images; not for a frame split / --virtual-world)
+        whole_groups = gs == 0 or args.shared_by_group or (not distributed and vworld == 1)
+        hip_sample = hip_rows(out, n_cpu) if whole_groups else None
     if solo and args.secondary and args.camera_model == "pinhole":
         del data, out
         torch.cuda.empty_cache()
         extras["secondary"] = {
-            f"simple_radial_B{B}": quick_case(lib, LMOptimizer, synth_fields, dev, "simple_radial", B, H, W, args.lm_steps, args.seed, 0),
-            "shared16_pinhole": quick_case(lib, LMOptimizer, synth_fields, dev, "pinhole", B, H, W, args.lm_steps, args.seed, 16),
+            f"simple_radial_B{B}": quick_case(lib, LMOptimizer, synth_fields, dev, "simple_radial", B, H, W, args.lm_steps, args.seed, 0,
+                                              oracle_images=64 if args.cpu_sample != 0 else 0, slat_control=True),
+            "shared16_pinhole": quick_case(lib, LMOptimizer, synth_fields, dev, "pinhole", B, H, W, args.lm_steps, args.seed, 16,
+                                           oracle_images=64 if args.cpu_sample != 0 else 0),
         }
+
+    def same_bits(a, b):
+        return bool(((a == b) | (a.isnan() & b.isnan())).all())
+
+    def gathered_parity():
+        """Image / group sharding: rank 0 re-generates the shard of ANOTHER rank from (seed, first index) -- the generator is
+        index-keyed -- solves it alone and compares the rows the all-gather delivered for that rank, bit for bit: proves that
+        the collective returned every rank's rows in rank order and unscrambled (the gathered rows of rank r ARE a one-GPU
+        solve of the images [rB, (r+1)B) by construction)."""
+        r = world - 1
+        d2, _, _ = synth_fields(args.camera_model, B, H, W, dev, seed=args.seed, first_index=r * B, group_size=gs or 1)
+        alone = opt(d2)
+        torch.cuda.synchronize()
+        keys = [k for k in alone if torch.is_tensor(alone[k]) or hasattr(alone[k], "_data")]
+        diff = []
+        for k in keys:
+            a = alone[k]._data if hasattr(alone[k], "_data") else alone[k]
+            g = out[k]._data if hasattr(out[k], "_data") else out[k]
+            if not same_bits(a, g[r * B:(r + 1) * B]):
+                diff.append(k)
+        return {"kind": "gathered rows of one rank vs a one-GPU solve of the same images on rank 0", "rank_checked": r,
+                "images": B, "keys_compared": len(keys), "bit_identical": not diff, "keys_differing": diff}
+
+    def split_parity():
+        """Frame split (one all-reduce per LM step): rank 0 solves up to 4 WHOLE groups alone (shared intrinsics, one launch
+        sequence, no collective) and records how far its own frames of those groups came out in the split run -- the first
+        observation of the collective's summation order (expected ~1e-6, gate 1e-4)."""
+        if vworld != world:
+            return {"kind": "frame split vs whole groups solved on rank 0", "skipped": f"--virtual-world {vworld}: the {world} rank(s) "
+                    "of this run hold only part of every group, the sum over them is not the whole group's system"}
+        ng = min(4, n_groups)
+        d2, _, _ = synth_fields(args.camera_model, ng * gs, H, W, dev, seed=args.seed, first_index=0, group_size=gs)
+        opt2 = LMOptimizer({**conf, "shared_intrinsics": True, "group_size": gs}).eval()
+        alone = opt2(d2)
+        torch.cuda.synchronize()
+        loc = torch.arange(ng * fpg, device=dev)
+        idx = (loc // fpg) * gs + lay["first_index"] + loc % fpg           # this rank's frames inside the whole groups
+        f = (out["camera"]._data[:ng * fpg, 2:4] / alone["camera"]._data[idx, 2:4] - 1).abs().max().item()
+        g = (out["gravity"]._data[:ng * fpg] - alone["gravity"]._data[idx]).abs().max().item()
+        c = (out["final_cost"][:ng * fpg] / alone["final_cost"][idx] - 1).abs().max().item()
+        return {"kind": "frame split vs whole groups solved on rank 0", "groups_checked": ng, "frames_compared": ng * fpg,
+                "max_focal_rel": f, "max_gravity_abs": g, "max_final_cost_rel": c, "gate": ORACLE_GATE,
+                "within_gate": bool(all(x == x and x <= ORACLE_GATE for x in (f, g, c)))}
 
     if "best_of_n" not in placement:
         placement["tries"] = 1            # (N > 1, shared intrinsics, --streams: the first allocation and nothing else)
@@ -600,23 +770,29 @@ def main():
                 "launched_by": "bench.py itself (torch.distributed.run child)" if os.environ.get("GCLM_BENCH_SELF_LAUNCHED") == "1"
                                else "an external launcher",
                 "rccl": rccl_versions(lib)}
+            try:
+                result["multi_gpu"]["parity"] = gathered_parity() if gs == 0 or args.shared_by_group else split_parity()
+            except Exception as e:      # (a failing check is reported, it does not take the measurement down)
+                result["multi_gpu"]["parity"] = {"error": repr(e)}
         if sweep_n and all(t > 0 for t in per_rank_sweep_ms):
             # every rank's own mean sweep launch; the line's `frac` / `achieved` are the SLOWEST rank's (N = 1: the only one)
             per_rank_frac = [round(algo_frac(t), 4) for t in per_rank_sweep_ms]
             avg_ms = max(per_rank_sweep_ms)
             achieved = algo_bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            traffic = None
+            traffic, tsrc = None, ""
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tpath):
                 with open(tpath) as fh:
                     t = json.load(fh)
                 key = f"{args.camera_model}_B{B}_{W}x{H}"
                 traffic = t.get(key, {}).get("hbm_bytes_per_launch")
+                tsrc = t.get(key, {}).get("source", "")
             result["roofline"] = {
                 "bound": "hbm", "kernel": "gclm::sweep_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command, committed; not "
-                                  "re-measured in this run)" if traffic is not None else None,
+                "traffic_source": (f"profiles/pmc_traffic.json ({tsrc}): rocprofv3 --pmc passes of this command on ANOTHER "
+                                   "box and allocation than this run's, committed; not re-measured here (PMC needs rocprofv3 "
+                                   "around the process)") if traffic is not None else None,
                 "algorithmic_bytes_per_launch": algo_bytes_per_launch, "avg_launch_ms": round(avg_ms, 4),
                 "launches_timed": sweep_n, "per_rank_frac": per_rank_frac,
                 "per_rank_avg_launch_ms": [round(t, 4) for t in per_rank_sweep_ms],
@@ -624,11 +800,28 @@ def main():
                                 f"solve {args.streams} parts of the batch concurrently, whose launch durations overlap and are "
                                 "not separable" if overlapped else "the timed regions"),
                 "whole_job_frac": round(value / world * (args.lm_steps + 1) * H * W * PLANES * 4 / 1e9 / HBM_PEAK_GBS, 4)}
+            if all(x > 0 for x in per_rank_rc):
+                # what the SAME buffers stream with the sweep's load and no arithmetic (gclm_read_probe, 5 launches right
+                # after the timed regions): how much of `frac` is the allocation / box, how much the kernel
+                result["roofline"].update(
+                    read_ceiling_frac=round(per_rank_rc[per_rank_sweep_ms.index(avg_ms)], 4),
+                    frac_of_read_ceiling=round(achieved / HBM_PEAK_GBS / per_rank_rc[per_rank_sweep_ms.index(avg_ms)], 4),
+                    per_rank_read_ceiling_frac=[round(x, 4) for x in per_rank_rc],
+                    read_ceiling="gclm_read_probe over this rank's five timed planes: non-temporal 16 B / lane loads, four per "
+                                 "plane in flight per thread, no arithmetic; mean of 5 launches after the timed regions")
         if host_sample is not None:      # (the baselines time independent solves: configs[1] / [3])
+            kept = {}
             try:
-                result["cpu_baseline"] = cpu_baseline(args, next(iter(host_sample.values())).shape[0], host_sample)
+                result["cpu_baseline"] = cpu_baseline(args, next(iter(host_sample.values())).shape[0], host_sample, keep=kept)
             except Exception as e:  # the checker must never take the product measurement down
                 result["cpu_baseline"] = {"value": None, "error": repr(e)}
+            if hip_sample is not None and kept:
+                n_ref = kept["camera"].shape[0]
+                result["check"]["vs_oracle"] = vs_oracle(
+                    hip_sample, kept, f"the first {n_ref} images of rank 0's timed batch"
+                    + (f" as {n_ref // gs} shared-intrinsics groups of {gs}" if gs else "") + " (the cpu_baseline sample)")
+            elif hip_sample is None:
+                result["check"]["vs_oracle"] = None       # (a frame split: rank 0's frames are no sub-problem; see multi_gpu.parity)
         emit(result)
     if distributed:
         dist.destroy_process_group()

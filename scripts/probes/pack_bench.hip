@@ -17,8 +17,11 @@ template <bool NT> __device__ __forceinline__ void st(float* p, v4 v) {
     else *reinterpret_cast<v4*>(p) = v;
 }
 // MATH 0: copy; 1: the epilogue.  UNR: float4 units per thread and iteration
+// The copy multiplies by `one`, a kernel argument that is 1.0f at run time: round 5's copy stored each value back to the
+// address it was loaded from unchanged, the compiler removed loads and stores, and the "ceiling" read 47x the HBM peak
+// (VERDICT r05 #5).  x * one cannot be folded, costs one packed multiply per float4 and leaves the traffic what it is.
 template <bool NTL, bool NTS, int MATH, int UNR>
-__global__ __launch_bounds__(256) void k_pack(float* up, float* upc, float* lat, float* latc, int B, size_t N) {
+__global__ __launch_bounds__(256) void k_pack(float* up, float* upc, float* lat, float* latc, int B, size_t N, float one) {
     const size_t units = N / 4;
     for (int b = blockIdx.y; b < B; b += gridDim.y) {
         float* ox = up + (size_t)b * 2 * N;
@@ -37,6 +40,7 @@ __global__ __launch_bounds__(256) void k_pack(float* up, float* upc, float* lat,
             for (int u = 0; u < UNR; ++u) {
                 const size_t i = i0 + (size_t)u * 256;
                 if (i >= units) continue;
+                if (!MATH) { a[u] *= one; bq[u] *= one; l[u] *= one; c1[u] *= one; c2[u] *= one; }
                 if (MATH) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -52,7 +56,7 @@ __global__ __launch_bounds__(256) void k_pack(float* up, float* upc, float* lat,
         }
     }
 }
-struct V { const char* name; void (*k)(float*, float*, float*, float*, int, size_t); int unr; int bx; };
+struct V { const char* name; void (*k)(float*, float*, float*, float*, int, size_t, float); int unr; int bx; };
 int main() {
     const int H = 480, W = 640;
     const size_t N = (size_t)H * W;
@@ -63,13 +67,15 @@ int main() {
         {"nt loads", k_pack<true, false, 1, 1>, 1, 128},
         {"nt loads + nt stores", k_pack<true, true, 1, 1>, 1, 128},
         {"nt stores", k_pack<false, true, 1, 1>, 1, 128},
-        {"copy, plain", k_pack<false, false, 0, 1>, 1, 128},
-        {"copy, nt both", k_pack<true, true, 0, 1>, 1, 128},
+        {"copy (x * 1.0f), plain", k_pack<false, false, 0, 1>, 1, 128},
+        {"copy (x * 1.0f), nt both", k_pack<true, true, 0, 1>, 1, 128},
+        {"copy (x * 1.0f), nt both, grid 300", k_pack<true, true, 0, 1>, 1, 300},
         {"nt both, 2 units / thread", k_pack<true, true, 1, 2>, 2, 64},
         {"nt both, grid 300 (one pass)", k_pack<true, true, 1, 1>, 1, 300},
         {"nt both, grid 32", k_pack<true, true, 1, 1>, 1, 32},
         {"plain, grid 300 (one pass)", k_pack<false, false, 1, 1>, 1, 300},
     };
+    const float one = getenv("PACK_BENCH_SCALE") ? (float)atof(getenv("PACK_BENCH_SCALE")) : 1.0f;     // run-time value
     for (int B : {256, 1024}) {
         float *up, *upc, *lat, *latc;
         CK(hipMalloc(&up, (size_t)B * 2 * N * 4)); CK(hipMalloc(&upc, (size_t)B * N * 4)); CK(hipMalloc(&lat, (size_t)B * N * 4)); CK(hipMalloc(&latc, (size_t)B * N * 4));
@@ -83,17 +89,17 @@ int main() {
             for (int b = 0; b < B; ++b) CK(hipMemcpyAsync(up + (size_t)b * 2 * N, h.data(), N * 2 * 4, hipMemcpyHostToDevice, s));
             CK(hipMemsetAsync(upc, 0, (size_t)B * N * 4, s)); CK(hipMemsetAsync(lat, 0, (size_t)B * N * 4, s)); CK(hipMemsetAsync(latc, 0, (size_t)B * N * 4, s));
             const dim3 grid(v.bx, B < 4096 ? B : 4096);
-            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(v.k, grid, dim3(256), 0, s, up, upc, lat, latc, B, N);
+            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(v.k, grid, dim3(256), 0, s, up, upc, lat, latc, B, N, one);
             CK(hipStreamSynchronize(s));
             float best = 1e30f, sum = 0;
             for (int rep = 0; rep < 3; ++rep) {
                 CK(hipEventRecord(e0, s));
-                for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(v.k, grid, dim3(256), 0, s, up, upc, lat, latc, B, N);
+                for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(v.k, grid, dim3(256), 0, s, up, upc, lat, latc, B, N, one);
                 CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10; sum += ms; if (ms < best) best = ms;
             }
             CK(hipGetLastError());
-            printf("  %-32s mean %8.1f us  best %8.1f us = %5.2f TB/s (%.3f of 8)\n", v.name, sum / 3 * 1e3, best * 1e3, bytes / (sum / 3 * 1e-3) / 1e12, bytes / (sum / 3 * 1e-3) / 8e12);
+            printf("  %-36s mean %8.1f us  best %8.1f us = %5.2f TB/s (%.3f of 8)\n", v.name, sum / 3 * 1e3, best * 1e3, bytes / (sum / 3 * 1e-3) / 1e12, bytes / (sum / 3 * 1e-3) / 8e12);
             fflush(stdout);
         }
         CK(hipFree(up)); CK(hipFree(upc)); CK(hipFree(lat)); CK(hipFree(latc));

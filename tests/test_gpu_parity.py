@@ -1298,6 +1298,17 @@ def test_bench_multi_rank_path_on_one_gpu(dev, extra):
     elif split:
         assert mg["collective_bytes"] == 8 * 32 * 4                      # 128 frames = 8 groups of 16, split over the 2 ranks
     assert len(out["ms_per_step_repeats"]) == out["repeats"] == 3
+    # every N > 1 line carries a parity check of its own: the rows the gather delivered for the OTHER rank are
+    # bit for bit a one-GPU solve of that rank's images; a frame split lands within 1e-4 of whole groups solved on rank 0
+    par = mg["parity"]
+    if "--virtual-world" in extra:
+        assert "skipped" in par
+    elif split:
+        assert par["groups_checked"] == 4 and par["frames_compared"] == 32 and par["within_gate"] is True, par
+        assert max(par["max_focal_rel"], par["max_gravity_abs"], par["max_final_cost_rel"]) < 1e-4
+    else:
+        assert par["rank_checked"] == 1 and par["images"] == 64 and par["bit_identical"] is True and par["keys_compared"] >= 10, par
+    assert all(0 < f <= 1.05 for f in out["roofline"]["per_rank_read_ceiling_frac"])
 
 
 @pytest.mark.parametrize("extra", [[], ["--shared-group", "16"]])
@@ -1329,6 +1340,14 @@ def test_bench_starts_its_own_ranks(dev, extra):
     assert len(rf["per_rank_frac"]) == 2 and all(0 < f < 1 for f in rf["per_rank_frac"]) and rf["frac"] == min(rf["per_rank_frac"])
     assert "best_of_n" not in out["placement"] and out["placement"]["solve_ms"] is None
     assert mg["rccl"]["compiled"] >= 22000 and mg["rccl"]["runtime"] >= 22000
+    # ... and carries its own parity: the gathered rows of rank 1 / the split result against a one-GPU solve, and rank 0's
+    # first images against the CPU oracle (independent images; rank 0's slice of a frame split is no sub-problem of its own)
+    if extra:
+        assert mg["parity"]["within_gate"] is True and out["check"]["vs_oracle"] is None
+    else:
+        assert mg["parity"]["bit_identical"] is True and mg["parity"]["rank_checked"] == 1
+        vo = out["check"]["vs_oracle"]
+        assert vo["images"] == 2 and vo["within_gate"] is True and vo["gate"] == 1e-4 and vo["max_focal_rel"] < 1e-4, vo
     # with the real backend two ranks need two GPUs: on a one-GPU box the answer is ONE JSON line with an error, not a trace
     if torch.cuda.device_count() < 2:
         res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "64"], capture_output=True,
@@ -1362,6 +1381,22 @@ def test_bench_single_gpu_line_carries_secondary_overlap_and_best_of_n(dev):
     for rec in sec.values():
         assert rec["value"] > 0 and rec["steps"] == 5 and rec["roofline"]["launches_timed"] == 5 * 21
         assert 0 < rec["roofline"]["frac"] < 1 and rec["check"]["median_focal_rel_err_vs_gt"] < 5e-3
+        # parity INSIDE the record: the first 64 images of the timed batch against the CPU oracle
+        vo = rec["check"]["vs_oracle"]
+        assert vo["images"] == 64 and vo["within_gate"] is True and vo["gate"] == 1e-4, vo
+        assert max(vo["max_focal_rel"], vo["max_gravity_abs"], vo["max_final_cost_rel"]) <= 1e-4
+        assert 0 < rec["roofline"]["frac"] <= rec["roofline"]["read_ceiling_frac"] * 1.02 <= 1.05
+    # ... and the control for the scratch plane on the driver's own box: the same solves with the plane off, then on again
+    sr = sec["simple_radial_B832"]
+    assert sr["slat_plane_bytes"] == 832 * 480 * 640 * 4 and sr["workspace_bytes"] - sr["slat_plane_bytes"] < 16 * 2 ** 20
+    so = sr["slat_off"]
+    assert so["bit_identical"] is True and so["value"] > 0 and 0 < so["frac"] < 1 and so["on_again"]["value"] > 0
+    assert sec["shared16_pinhole"]["slat_plane_bytes"] == 0 and "slat_off" not in sec["shared16_pinhole"]
+    vo = out["check"]["vs_oracle"]
+    assert vo["images"] == 4 and vo["within_gate"] is True and vo["max_focal_rel"] < 1e-4, vo
+    rf = out["roofline"]
+    assert 0 < rf["frac"] <= rf["read_ceiling_frac"] * 1.02 <= 1.05 and abs(rf["frac_of_read_ceiling"] - rf["frac"] / rf["read_ceiling_frac"]) < 2e-3
+    assert "ANOTHER box" in (rf["traffic_source"] or "ANOTHER box")
     assert sec["shared16_pinhole"]["unit"] == "frames/sec" and "configs[4]" in sec["shared16_pinhole"]["workload"]
     ov = out["overlap"]
     assert ov["streams"] == 2 and ov["value"] > 0 and ov["bit_identical"] is True
@@ -1500,6 +1535,12 @@ def test_bench_collectives_through_rccl_with_one_rank(dev, extra):
     assert v["compiled"] == 22707 and v["runtime"] // 10000 == 2
     if "--comm" in extra:
         assert "gclm_comm_" in out["multi_gpu"]["comm"]
+    # the line's own parity block, through the REAL collective (one rank: its own shard / whole groups)
+    par = out["multi_gpu"]["parity"]
+    if "--shared-group" in extra:
+        assert par["groups_checked"] == 4 and par["within_gate"] is True, par
+    else:
+        assert par["rank_checked"] == 0 and par["bit_identical"] is True, par
 
 
 @pytest.mark.gpu
