@@ -587,8 +587,7 @@ static int run_solve(gclm_handle* h, const float* d_up, const float* d_lat, cons
     c.B = B; c.H = H; c.W = W; c.nchunks = geo.nchunks;
     // trivial / heuristic initial estimate without `scales`: fx == fy at the start, and update_focal keeps the ratio
     // (camera.py:148) -- the final sweep may then run the cheaper log-focal instantiation (see finalize_kernel)
-    // (only where the sweep HAS a log-focal instantiation: a -DGCLM_LOGF=0 build of gclm_pass.hip takes the general column)
-    c.iso_final = (ia.cam == nullptr && ia.scales == nullptr && GCLM_ISO_FINAL && sweep_has_log_focal()) ? 1 : 0;
+    c.iso_final = (ia.cam == nullptr && ia.scales == nullptr && GCLM_ISO_FINAL) ? 1 : 0;
     if (int rc = setup_groups(h, B)) return rc;
     const bool es = h->cfg.early_stop != 0;
     const bool fused_path = use_fused(h, B, geo);

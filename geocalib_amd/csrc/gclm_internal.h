@@ -154,7 +154,6 @@ constexpr unsigned kPacedStopBit = 1u << 16;
 constexpr unsigned kPacedEpochShift = 20, kPacedEpochMask = 0xfffu;
 constexpr int kPacedPatienceUs = 2000;    // host wait for one report before the rest of the solve is issued unpaced ...
 constexpr int kPacedCooldown = 64;        // ... and solves of that handle that then do not pace at all
-bool sweep_has_log_focal();               // gclm_pass.hip: false in a -DGCLM_LOGF=0 measurement build
 bool sweep_has_slat_plane(int camera_model);   // gclm_pass.hip: the model's five-plane float4 sweep has the SLAT instantiations
 constexpr int kMaxMergeParts = 8;
 struct MergeStopArgs {          // gclm_merge_stop_at: parts of one batch solved by separate handles

@@ -48,6 +48,7 @@
 #include "gclm_internal.h"
 #include "gclm_device.h"
 
+// waves per SIMD the float4 sweeps are held to (launch bounds of sweep_kernel); measurement builds override them
 #ifndef GCLM_MIN_WAVES
 #define GCLM_MIN_WAVES 1
 #endif
@@ -57,56 +58,12 @@
 #ifndef GCLM_PINHOLE_WAVES
 #define GCLM_PINHOLE_WAVES 6
 #endif
-#ifndef GCLM_LOGF
-#define GCLM_LOGF 1            // A/B switch: 0 = always the general focal-column code
-#endif
-#ifndef GCLM_XCD_REMAP
-#define GCLM_XCD_REMAP 0
-#endif
-#ifndef GCLM_DPP_REDUCE
-#define GCLM_DPP_REDUCE 1
-#endif
-#ifndef GCLM_DIV_LITERAL
-#define GCLM_DIV_LITERAL 0
-#endif
 #ifndef GCLM_RADIAL_WAVES
 #define GCLM_RADIAL_WAVES 3
 #endif
-#ifndef GCLM_RADIAL_DOT
-#define GCLM_RADIAL_DOT 1           // A/B switch: 0 = radial keeps the explicit-ray latitude block
-#endif
-#ifndef GCLM_FENCE_PROBE
-#define GCLM_FENCE_PROBE 0
-#endif
-#ifndef GCLM_BUFFER_AUX
-#define GCLM_BUFFER_AUX -1
-#endif
-#ifndef GCLM_NT_LOADS
-#define GCLM_NT_LOADS 1
-#endif
-#ifndef GCLM_RAY_FACTORED
-#define GCLM_RAY_FACTORED 1         // A/B switch: 0 = (e/n)(x_xy.uv) + x_z/n form of the latitude dot products (rounds 1-3)
-#endif
-#ifndef GCLM_HUBER_CLAMP
-#define GCLM_HUBER_CLAMP 1          // A/B switch: 0 = min(1, rsq) as a separate v_min_f32 (rounds 1-3)
-#endif
-#ifndef GCLM_EPS_FMA
-#define GCLM_EPS_FMA 1              // A/B switch: 0 = max(|q|^2, 1e-24) as a separate v_max_f32 (rounds 1-3)
-#endif
 #ifndef GCLM_SLAT_PINHOLE
-#define GCLM_SLAT_PINHOLE 1         // the pinhole sweep has the sin(latitude) scratch-plane instantiations too; the library's
-                                    // built-in choice does not use them (memory-bound: the plane's one extra write costs
-                                    // what the saved VALU work gains), gclm_set_slat_plane(h, 1) does (measurement)
-#endif
-#ifndef GCLM_ORDER
-#define GCLM_ORDER 0                // A/B switch: the order in which workgroups visit (image, chunk), see sweep_kernel
-#endif
-#ifndef GCLM_DIV_SQRT_REFINE
-#define GCLM_DIV_SQRT_REFINE 1      // A/B switch: 0 = simple_divisional takes v_sqrt_f32 as it comes (rounds 2-4)
-#endif
-#ifndef GCLM_DIV_GUARD_ALWAYS
-#define GCLM_DIV_GUARD_ALWAYS 0     // A/B switch: 1 = simple_divisional always runs the guarded body (round-2 behaviour)
-#endif
+#define GCLM_SLAT_PINHOLE 1    // pinhole has the scratch-plane instantiations too: never the built-in choice (memory-bound), only
+#endif                         // gclm_set_slat_plane(h, 1) launches them (measurement)
 
 #ifndef GCLM_TRACE
 #define GCLM_TRACE 0                // measurement build only: device timestamps of one workgroup's stages (scripts/probes/trace_probe.py)
@@ -136,41 +93,25 @@ __device__ __forceinline__ float vfma(float a, float b, float c) { return fmaf(a
 __device__ __forceinline__ f2 vfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ float vrsq(float a) { return __frsqrt_rn(a); }
 __device__ __forceinline__ f2 vrsq(f2 a) { return f2{__frsqrt_rn(a.x), __frsqrt_rn(a.y)}; }
-__device__ __forceinline__ float vrcp(float a) { return __frcp_rn(a); }
-__device__ __forceinline__ f2 vrcp(f2 a) { return f2{__frcp_rn(a.x), __frcp_rn(a.y)}; }
 // 1-ulp hardware forms (v_rcp_f32 / v_sqrt_f32) for simple_divisional, whose thirteen quotients would otherwise
 // each expand into the ~10-instruction correctly-rounded sequences
 __device__ __forceinline__ float vrcp_hw(float a) { return __builtin_amdgcn_rcpf(a); }
 __device__ __forceinline__ f2 vrcp_hw(f2 a) { return f2{__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}; }
 __device__ __forceinline__ float vsqrt_hw(float a) { return __builtin_amdgcn_sqrtf(a); }
 __device__ __forceinline__ f2 vsqrt_hw(f2 a) { return f2{__builtin_amdgcn_sqrtf(a.x), __builtin_amdgcn_sqrtf(a.y)}; }
-__device__ __forceinline__ float vsqrt(float a) { return __fsqrt_rn(a); }
-__device__ __forceinline__ f2 vsqrt(f2 a) { return f2{__fsqrt_rn(a.x), __fsqrt_rn(a.y)}; }
 __device__ __forceinline__ float vmax(float a, float b) { return fmaxf(a, b); }
 __device__ __forceinline__ f2 vmax(f2 a, f2 b) { return f2{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
 __device__ __forceinline__ float vclamp(float a, float lo, float hi) { return fminf(fmaxf(a, lo), hi); }
 __device__ __forceinline__ f2 vclamp(f2 a, float lo, float hi) {
     return f2{fminf(fmaxf(a.x, lo), hi), fminf(fmaxf(a.y, lo), hi)};
 }
-// min(a, 1)
-__device__ __forceinline__ float vmin1(float a) { return fminf(a, 1.0f); }
-__device__ __forceinline__ f2 vmin1(f2 a) { return f2{fminf(a.x, 1.0f), fminf(a.y, 1.0f)}; }
 // min(1, 1/sqrt(y)) for y >= 0 in ONE instruction: v_rsq_f32 with the VOP3 clamp bit (the result is clamped to [0, 1];
 // rsq >= 0, rsq(0) = +inf -> 1).  Same bits as v_rsq_f32 + v_min_f32 for every y that is not NaN.
 __device__ __forceinline__ float vrsq_min1(float y) {
-#if GCLM_HUBER_CLAMP
     return __builtin_amdgcn_fmed3f(__frsqrt_rn(y), 0.0f, 1.0f);      // folded into the rsq's clamp bit (no inline asm:
                                                                      // the compiler keeps track of the trans-use hazard)
-#else
-    return fminf(__frsqrt_rn(y), 1.0f);
-#endif
 }
 __device__ __forceinline__ f2 vrsq_min1(f2 y) { return f2{vrsq_min1(y.x), vrsq_min1(y.y)}; }
-// select(y <= 1, a, b)
-__device__ __forceinline__ float vsel_le1(float y, float a, float b) { return y <= 1.0f ? a : b; }
-__device__ __forceinline__ f2 vsel_le1(f2 y, f2 a, f2 b) {
-    return f2{y.x <= 1.0f ? a.x : b.x, y.y <= 1.0f ? a.y : b.y};
-}
 // denominator guard of the reference: x.masked_fill(x == 0, 1e6)
 __device__ __forceinline__ float vguard(float a) { return a == 0.f ? 1e6f : a; }
 __device__ __forceinline__ f2 vguard(f2 a) { return f2{a.x == 0.f ? 1e6f : a.x, a.y == 0.f ? 1e6f : a.y}; }
@@ -220,17 +161,10 @@ __device__ __forceinline__ F sin_halfpi(F x) { return sin_halfpi(x, x * x); }
 template <typename F>
 __device__ __forceinline__ F huber_accumulate(F x2, float inv_a2, F conf, F& cost_acc) {
     const F y = x2 * inv_a2;
-#if GCLM_HUBER_SELECT      // A/B switch: the reference's literal select form
-    const F isx = vrsq(y + 1e-8f);
-    const F weight = vsel_le1(y, vsplat(y, 1.0f), isx);
-    cost_acc = vfma(vsel_le1(y, y, vfma(2.0f * (y + 1e-8f), isx, vsplat(y, -1.0f))), conf, cost_acc);
-    return weight * conf;
-#else
     const F weight = vrsq_min1(y);
     const F wc = weight * conf;
     cost_acc = vfma(y * wc, 2.0f - weight, cost_acc);
     return wc;
-#endif
 }
 
 struct HuberK {
@@ -277,44 +211,6 @@ __device__ __forceinline__ void radial_terms(const PBlock& P, F r2, Radial<F>& R
         R.dtau[0] = vfma(r4, vsplat(r2, 6.0f * P.k1), -r2);
         R.dtau[1] = -r4;
     } else if constexpr (MODEL == GCLM_SIMPLE_DIVISIONAL) {      // camera.py:829-940, guards as there
-#if GCLM_DIV_LITERAL      // A/B switch: the reference's thirteen literal quotients (correctly-rounded divisions)
-        const float k = P.k1;
-        const F tt = vfma(r2, vsplat(r2, -4.0f * k), one);           // 1 - 4 k r2
-        const F den = r2 * (2.0f * k);
-        R.s = vsel_eq0(den, one, (one - vsqrt(vmax(tt, zero))) * vrcp(vguard(den)));
-        const F t0 = vmax(tt, vsplat(r2, 1e-6f));
-        const F t1 = vsqrt(t0), it1 = vrcp(t1);
-        const F omt = one - t1;
-        const F r4 = r2 * r2;
-        {   // J_distort scale2pts (:843-851): off = uv (4 d2 - (1-t1) d1)/(d1 d2), d1 = 2 t1 r2, d2 = k r4
-            const F d1 = t1 * (2.0f * r2), d2 = r4 * k;
-            R.s1x2 = vfma(d2, vsplat(r2, 4.0f), -(omt * d1)) * vrcp(vguard(d1 * d2));
-        }
-        {   // J_up_projection_offset wrt uv (:912-940): diagonal jd and the uv uv^T coefficient
-            R.jd = 4.0f * vrcp(vguard(2.0f * r2 * t1)) - omt * vrcp(vguard(r4 * k));
-            F pc = -16.0f * vrcp(vguard(4.0f * t1 * r4));
-            pc = pc + (32.0f * k) * vrcp(vguard(4.0f * r2 * t0 * t1));
-            pc = pc - 4.0f * vrcp(vguard(r4 * t1));
-            pc = pc + 4.0f * omt * vrcp(vguard(r4 * r2 * k));
-            R.s2x4 = pc;
-        }
-        {   // J_distort scale2dist (:853-857)
-            const F d1 = t1 * (2.0f * k), d2 = r2 * (2.0f * k * k);
-            R.ds[0] = vfma(d2, vsplat(r2, 2.0f), -(omt * d1)) * vrcp(vguard(d1 * d2));
-        }
-        {   // J_up_projection_offset wrt dist (:898-911)
-            F J = 16.0f * vrcp(vguard(4.0f * t0 * t1));
-            J = J - 2.0f * vrcp(vguard(r2 * t1 * k));
-            const F rk = r2 * k;
-            J = J + omt * vrcp(vguard(rk * rk));
-            R.ds1x2[0] = J;
-        }
-        const F den2 = vfma(r2, vsplat(r2, k), one);                  // 1 + k r2
-        R.tau = vrcp(vguard(den2));
-        R.tau1x2 = (-2.0f * k) * R.tau * R.tau;                        // :878-883
-        R.dtau[0] = -r2 * vrcp(vguard(den2 * den2));                   // :875-877
-        (void)it1;
-#else
         // The reference divides by thirteen different products of {r2, t1 = sqrt(max(1 - 4 k r2, 1e-6)), k} and
         // replaces a denominator that is exactly 0 by 1e6 (masked_fill).  t1 >= 1e-3, so a product vanishes iff
         // r2 == 0 (indicator r2) or, where k is a factor, r2 k == 0 (indicator rk): every guarded reciprocal is
@@ -326,24 +222,16 @@ __device__ __forceinline__ void radial_terms(const PBlock& P, F r2, Radial<F>& R
         const F rk = r2 * k;
         const F tiny = vsplat(r2, 1e-6f);
         const F t0 = vmax(tt, tiny);
-#if GCLM_DIV_SQRT_REFINE
-        // 1 - sqrt(1 - 4 k r2) cancels: one ulp of the root is 1 / (2 |k| r2) ulps of the difference, and v_sqrt_f32's
-        // ulp is not a zero-mean rounding like the correctly rounded root the reference takes (torch.sqrt) -- at
-        // |k| = 1e-3 the FINAL COST of an image came out 2e-4 off at parameters equal to 1e-7 (fuzz 15/0 after one LM
-        // step; the oracle's float32 build: 3e-6).  One Newton step on the exact fma residual brings the hardware root
-        // to the correctly rounded one's accuracy (its error is again zero-mean) for three packed operations (+ two for 1 / t1).
-        // The reciprocal is stepped to the SAME point: the Jacobian terms below are cancelling sums of t1 and 1 / t1, and a
-        // root and a reciprocal that belong to two different points a few 1e-8 apart break those cancellations where the
-        // terms are large (fuzz 29/162: focal 3 px on a 118 px row, r2 = 340 -- twice the unrefined build's distance from the
-        // oracle per step, with the other sign, until an ill-conditioned step amplified it past the gate).
+        // 1 - sqrt(1 - 4 k r2) cancels: one ulp of the root is 1 / (2 |k| r2) ulps of the difference, and v_sqrt_f32's ulp is not
+        // a zero-mean rounding like the correctly rounded root the reference takes (at |k| = 1e-3 the final cost of an image came
+        // out 2e-4 off; the oracle's float32 build: 3e-6).  One Newton step on the exact fma residual brings the hardware root to
+        // the correctly rounded one's accuracy for three packed operations (+ two for 1 / t1).  The reciprocal is stepped to the
+        // SAME point: the Jacobian terms below are cancelling sums of t1 and 1 / t1, and a root and a reciprocal that belong to
+        // two points a few 1e-8 apart break those cancellations where the terms are large (fuzz 29/162; profiles/README.md).
         const F t1h = vsqrt_hw(t0), ih = vrcp_hw(t1h);
         const F t1 = vfma(vfma(-t1h, t1h, t0), 0.5f * ih, t1h);
         const F it1 = vfma(ih, vfma(-t1, ih, one), ih), it0 = it1 * it1;
         const F ssq = vsel_eq0(t0 - tt, t1, vsqrt_hw(vmax(tt, zero)));      // tt < 1e-6 (|4 k r2| ~ 1): nothing cancels there
-#else
-        const F ssq = vsqrt_hw(vmax(tt, zero));
-        const F t1 = vsqrt_hw(t0), it1 = vrcp_hw(t1), it0 = it1 * it1;
-#endif
         const F ir2 = vrcp_hw(r2), ir4 = ir2 * ir2, ir6 = ir4 * ir2;    // inf for r2 = 0: only read behind the selects
         const F omt = one - t1;
         const F r4 = r2 * r2;
@@ -377,7 +265,6 @@ __device__ __forceinline__ void radial_terms(const PBlock& P, F r2, Radial<F>& R
         R.tau = vrcp_hw(vguard(den2));
         R.tau1x2 = (-2.0f * k) * R.tau * R.tau;                        // :878-883
         R.dtau[0] = -r2 * vsel_eq0(den2, tiny, R.tau * R.tau);         // :875-877
-#endif
     }
 }
 
@@ -385,11 +272,7 @@ __device__ __forceinline__ void radial_terms(const PBlock& P, F r2, Radial<F>& R
 // 1e-24 rides in the fma chain -- it vanishes in the rounding unless |q|^2 < 1e-17 -- instead of a v_max_f32 per pixel.
 template <typename F>
 __device__ __forceinline__ F norm2_eps(F qx, F qy) {
-#if GCLM_EPS_FMA
     return vfma(qx, qx, vfma(qy, qy, vsplat(qx, 1e-24f)));
-#else
-    return vmax(vfma(qx, qx, qy * qy), vsplat(qx, 1e-24f));
-#endif
 }
 
 template <int MODEL>
@@ -516,7 +399,7 @@ __device__ __forceinline__ void pixel_accumulate_fast(const PBlock& P, const Hub
         const F guv = vfma(u, vsplat(u, P.ga), vsplat(u, v * P.gb));          // g_xy . uv
         F s, l0, l1;
         const F uT0 = vfma(u, vsplat(u, P.T00), vsplat(u, v * P.T10)), uT1 = vfma(u, vsplat(u, P.T01), vsplat(u, v * P.T11));
-        if constexpr (DIST && GCLM_RAY_FACTORED) {
+        if constexpr (DIST) {
             // ray . x = rnn (e (x_xy.uv) + x_z): the 1/n factor last -- one op per pixel pair less than
             // (e rnn)(x_xy.uv) + rnn x_z, which needs e rnn (pinhole: e = 1, no difference; it keeps the form below)
             s = vfma(e, guv, vsplat(u, P.gc)) * rnn;                                                // ray . g
@@ -685,115 +568,61 @@ __device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& 
         }
     }
 
-    // The dot-product form of the latitude block is 2-3 % faster for simple_divisional and the two fast-path models.
-    // radial (24 accumulator pairs, held to 168 VGPRs = 3 waves per SIMD) spills 12 bytes with it and is still 1.5 %
-    // faster than with the explicit ray (1200 vs 1220 us at B = 1024; at 2 waves per SIMD and no spill: 1265 us).
-    if constexpr (MODEL != GCLM_RADIAL || GCLM_RADIAL_DOT) {
-        {   // latitude (ray = (tau u, tau v, 1)/n only through dot products, see pixel_accumulate_fast)
-            const F tr2 = DIST ? R.tau * r2 : r2;
-            const F nn = DIST ? vfma(R.tau, tr2, vsplat(u, 1.0f)) : r2 + 1.0f;
-            const F rnn = vrsq(nn);
-            const F guv = vfma(u, vsplat(u, P.ga), vsplat(u, v * P.gb));
-            const F uT0 = vfma(u, vsplat(u, P.T00), vsplat(u, v * P.T10)), uT1 = vfma(u, vsplat(u, P.T01), vsplat(u, v * P.T11));
-            F s_, l[PN];
-            [[maybe_unused]] F trn = rnn;
-            if constexpr (DIST && LOGF && GCLM_RAY_FACTORED) {       // ray . x = rnn (tau (x_xy.uv) + x_z), see the fast body
-                s_ = vfma(R.tau, guv, vsplat(u, P.gc)) * rnn;
-                l[0] = vfma(R.tau, uT0, vsplat(u, P.T20)) * rnn;
-                l[1] = vfma(R.tau, uT1, vsplat(u, P.T21)) * rnn;
-            } else {
-                trn = DIST ? R.tau * rnn : rnn;
-                s_ = vfma(trn, guv, rnn * P.gc);
-                l[0] = vfma(trn, uT0, rnn * P.T20);
-                l[1] = vfma(trn, uT1, rnn * P.T21);
-            }
-            const F sc = vclamp(s_, -1.0f + 1e-6f, 1.0f - 1e-6f);
-            const F rl = slat - sc;                          // lm_optimizer.py:262,270-271 (slat = sin(latitude_field))
-            const F wgt = huber_accumulate(rl * rl, hk.inv_a2l, cl, acc[A_CL]);
-            // ds/df = tau (h.w) + 2 tau1 (uv.w)(h.uv),  ds/dk_j = (dtau/dk_j)(h.uv)   (perspective_fields.py:255-272)
-            //   h.uv = rnn (g_xy.uv - s trn r2),   h.w = rnn (g_xy.w - s trn (uv.w))
-            [[maybe_unused]] F hu = vsplat(u, 0.f);
-            if constexpr (LOGF || DIST) hu = vfma(-s_, tr2 * rnn, guv) * rnn;
-            if constexpr (LOGF) {                            // h.w = -h.uv, uv.w = -r2
-                l[2] = -hu;
-                if constexpr (DIST) l[2] = -(hu * vfma(R.tau1x2, r2, R.tau));
-            } else {
-                const F gw = vfma(wx, vsplat(u, P.ga), vsplat(u, wy * P.gb));
-                const F hw = vfma(-s_, trn * uvw, gw) * rnn;
-                l[2] = hw;
-                if constexpr (DIST) l[2] = vfma(R.tau, hw, (R.tau1x2 * uvw) * hu);
-            }
-            if constexpr (DIST) {
-#pragma unroll
-                for (int j = 0; j < ND; ++j) l[3 + j] = R.dtau[j] * hu;
-            }
-            if constexpr (EMIT == 1) {
-                if (j_lat) {
-#pragma unroll
-                    for (int k = 0; k < PN; ++k) j_lat[k] = l[k];
-                }
-            } else if constexpr (EMIT == 2) {
-                if (j_lat) j_lat[0] = rl;
-            } else {
-                accumulate<MODEL>(acc, l, wgt, rl);
-            }
+    {   // latitude (ray = (tau u, tau v, 1)/n only through dot products, see pixel_accumulate_fast; the explicit-ray form
+        // measured 1.5-3 % slower for every model: profiles/README.md)
+        const F tr2 = DIST ? R.tau * r2 : r2;
+        const F nn = DIST ? vfma(R.tau, tr2, vsplat(u, 1.0f)) : r2 + 1.0f;
+        const F rnn = vrsq(nn);
+        const F guv = vfma(u, vsplat(u, P.ga), vsplat(u, v * P.gb));
+        const F uT0 = vfma(u, vsplat(u, P.T00), vsplat(u, v * P.T10)), uT1 = vfma(u, vsplat(u, P.T01), vsplat(u, v * P.T11));
+        F s_, l[PN];
+        [[maybe_unused]] F trn = rnn;
+        if constexpr (DIST && LOGF) {       // ray . x = rnn (tau (x_xy.uv) + x_z), see the fast body
+            s_ = vfma(R.tau, guv, vsplat(u, P.gc)) * rnn;
+            l[0] = vfma(R.tau, uT0, vsplat(u, P.T20)) * rnn;
+            l[1] = vfma(R.tau, uT1, vsplat(u, P.T21)) * rnn;
+        } else {
+            trn = DIST ? R.tau * rnn : rnn;
+            s_ = vfma(trn, guv, rnn * P.gc);
+            l[0] = vfma(trn, uT0, rnn * P.T20);
+            l[1] = vfma(trn, uT1, rnn * P.T21);
         }
-    } else {
-        {   // latitude
-            F Px = u, Py = vsplat(u, v);
-            if constexpr (DIST) {
-                Px = R.tau * u;
-                Py = R.tau * v;
-            }
-            const F nn = vfma(Px, Px, vfma(Py, Py, vsplat(u, 1.0f)));
-            const F rnn = vrsq(nn);
-            const F rayx = Px * rnn, rayy = Py * rnn;        // rayz = rnn
-            const F s_ = vfma(rayx, vsplat(u, P.ga), vfma(rayy, vsplat(u, P.gb), rnn * P.gc));
-            const F sc = vclamp(s_, -1.0f + 1e-6f, 1.0f - 1e-6f);
-            const F rl = slat - sc;                          // lm_optimizer.py:262,270-271 (slat = sin(latitude_field))
-            const F wgt = huber_accumulate(rl * rl, hk.inv_a2l, cl, acc[A_CL]);
-            F l[PN];
-            l[0] = vfma(rayx, vsplat(u, P.T00), vfma(rayy, vsplat(u, P.T10), rnn * P.T20));
-            l[1] = vfma(rayx, vsplat(u, P.T01), vfma(rayy, vsplat(u, P.T11), rnn * P.T21));
-            const F hx = vfma(-s_, rayx, vsplat(u, P.ga)) * rnn, hy = vfma(-s_, rayy, vsplat(u, P.gb)) * rnn;
-            // ds/df = tau (h.w) + 2 tau1 (uv.w)(h.uv),  ds/dk_j = (dtau/dk_j)(h.uv)   (perspective_fields.py:255-272)
-            if constexpr (LOGF) {                            // h.w = -h.uv, uv.w = -r2
-                const F hu = vfma(hx, u, hy * v);
-                l[2] = -hu;
-                if constexpr (DIST) {
-                    l[2] = -(hu * vfma(R.tau1x2, r2, R.tau));
-    #pragma unroll
-                    for (int j = 0; j < ND; ++j) l[3 + j] = R.dtau[j] * hu;
-                }
-            } else {
-                const F hw = vfma(hx, wx, hy * wy);
-                l[2] = hw;
-                if constexpr (DIST) {
-                    const F hu = vfma(hx, u, hy * v);
-                    l[2] = vfma(R.tau, hw, (R.tau1x2 * uvw) * hu);
-    #pragma unroll
-                    for (int j = 0; j < ND; ++j) l[3 + j] = R.dtau[j] * hu;
-                }
-            }
-            if constexpr (EMIT == 1) {
-                if (j_lat) {
+        const F sc = vclamp(s_, -1.0f + 1e-6f, 1.0f - 1e-6f);
+        const F rl = slat - sc;                          // lm_optimizer.py:262,270-271 (slat = sin(latitude_field))
+        const F wgt = huber_accumulate(rl * rl, hk.inv_a2l, cl, acc[A_CL]);
+        // ds/df = tau (h.w) + 2 tau1 (uv.w)(h.uv),  ds/dk_j = (dtau/dk_j)(h.uv)   (perspective_fields.py:255-272)
+        //   h.uv = rnn (g_xy.uv - s trn r2),   h.w = rnn (g_xy.w - s trn (uv.w))
+        [[maybe_unused]] F hu = vsplat(u, 0.f);
+        if constexpr (LOGF || DIST) hu = vfma(-s_, tr2 * rnn, guv) * rnn;
+        if constexpr (LOGF) {                            // h.w = -h.uv, uv.w = -r2
+            l[2] = -hu;
+            if constexpr (DIST) l[2] = -(hu * vfma(R.tau1x2, r2, R.tau));
+        } else {
+            const F gw = vfma(wx, vsplat(u, P.ga), vsplat(u, wy * P.gb));
+            const F hw = vfma(-s_, trn * uvw, gw) * rnn;
+            l[2] = hw;
+            if constexpr (DIST) l[2] = vfma(R.tau, hw, (R.tau1x2 * uvw) * hu);
+        }
+        if constexpr (DIST) {
 #pragma unroll
-                    for (int k = 0; k < PN; ++k) j_lat[k] = l[k];
-                }
-            } else if constexpr (EMIT == 2) {
-                if (j_lat) j_lat[0] = rl;
-            } else {
-                accumulate<MODEL>(acc, l, wgt, rl);
+            for (int j = 0; j < ND; ++j) l[3 + j] = R.dtau[j] * hu;
+        }
+        if constexpr (EMIT == 1) {
+            if (j_lat) {
+#pragma unroll
+                for (int k = 0; k < PN; ++k) j_lat[k] = l[k];
             }
+        } else if constexpr (EMIT == 2) {
+            if (j_lat) j_lat[0] = rl;
+        } else {
+            accumulate<MODEL>(acc, l, wgt, rl);
         }
     }
 }
 
-// wave64 sum.  DPP form (default): four in-row steps (quad_perm x2, row_half_mirror, row_mirror) leave the row sum
-// in every lane of each 16-lane row, row_bcast:15 / row_bcast:31 carry the rows along -- six v_add_f32 with DPP
-// operands, no LDS; the total is valid in lane 63 (kWaveSumLane).  The __shfl_xor butterfly costs six ds_bpermute
-// round trips per value (96 per workgroup epilogue).
-#if GCLM_DPP_REDUCE
+// wave64 sum: four in-row DPP steps (quad_perm x2, row_half_mirror, row_mirror) leave the row sum in every lane of each
+// 16-lane row, row_bcast:15 / :31 carry the rows along -- six v_add_f32 with DPP operands, no LDS (a __shfl_xor butterfly:
+// six ds_bpermute round trips per value); the total is valid in lane 63 (kWaveSumLane).
 constexpr int kWaveSumLane = 63;
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_add(float v) {
@@ -809,14 +638,6 @@ __device__ __forceinline__ float wave_sum(float v) {
     v = dpp_add<0x143, 0xC>(v);     // row_bcast:31 -> rows 2, 3
     return v;
 }
-#else
-constexpr int kWaveSumLane = 0;
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-#endif
 
 // Per-lane tile of one loop iteration: VEC = 4 -> one float4 per plane, processed as two packed
 // pixel pairs; VEC = 1 -> one pixel, scalar math (odd widths / unaligned pointers).
@@ -831,18 +652,9 @@ struct Lane<4> {
     static constexpr int kPairs = 2;
     static __device__ __forceinline__ V ld(const float* base, uint32_t byte_off) {
         typedef float v4 __attribute__((ext_vector_type(4)));
-#if GCLM_BUFFER_AUX >= 0   // A/B switch: buffer loads with an explicit cache policy (1 = sc0, 2 = nt, 16 = sc1)
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0xffffffffu, 0x00020000);
-        const v4 tb = __builtin_bit_cast(v4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, GCLM_BUFFER_AUX));
-        return make_float4(tb.x, tb.y, tb.z, tb.w);
-#endif
         const v4* p = reinterpret_cast<const v4*>(reinterpret_cast<const char*>(base) + byte_off);
-#if GCLM_NT_LOADS
         // every byte is read exactly once per sweep: stream it past the caches (global_load ... nt)
         const v4 t = __builtin_nontemporal_load(p);
-#else
-        const v4 t = *p;
-#endif
         return make_float4(t.x, t.y, t.z, t.w);
     }
     // the lane's four sin(latitude) values into the library's scratch plane (read back once per later sweep: streamed)
@@ -1053,7 +865,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const PBlock& P, 
     }
     // simple_divisional: can a guarded denominator vanish?  (k: wave-uniform; the column part of r2 == 0: loop invariant)
     [[maybe_unused]] bool col_zero = false;
-    [[maybe_unused]] const bool div_k_tiny = GCLM_DIV_GUARD_ALWAYS || !(fabsf(P.k1) >= 1e-20f);
+    [[maybe_unused]] const bool div_k_tiny = !(fabsf(P.k1) >= 1e-20f);
     if constexpr (MODEL == GCLM_SIMPLE_DIVISIONAL) {
 #pragma unroll
         for (int k = 0; k < L::kPairs; ++k) col_zero = col_zero || L::any_zero(col_u[k]);
@@ -1096,49 +908,16 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const PBlock& P, 
         if (tid == A_CL) s *= hk.a2l;
         a.partials[((size_t)b * a.nchunks + chunk) * NACC + tid] = s;
     }
-#if GCLM_FENCE_PROBE   // measurement only: what a "last workgroup of the image runs the update" scheme would pay per workgroup
-    // (release the record, count the image's finished workgroups with an agent-scope RMW; the counters live behind the records)
-    __syncthreads();
-    if (tid == 0) {
-        int* cnt = reinterpret_cast<int*>(a.partials + (size_t)a.B * a.nchunks * NACC) + b;
-#if GCLM_FENCE_PROBE == 1
-        const int seen = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-#else
-        const int seen = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-        if (seen == 0x7fffffff) a.partials[0] = 0.f;      // never: keeps the RMW's result alive
-    }
-#endif
 }
 
-// launch bounds: radial / simple_divisional are held to 168 VGPRs (3 waves per SIMD); simple_radial reaches 112 (4 waves)
-// on its own; the log-focal pinhole sweep is held to 80 (6 waves: the latitude range test of round 3 took it to 82
-// otherwise; the general-focal instantiation would spill at 80 and keeps its own 96, and so do the scratch-plane
-// instantiations SLAT != 0, which the library's built-in choice never launches for pinhole)
+// launch bounds: radial / simple_divisional are held to 168 VGPRs (3 waves per SIMD); simple_radial reaches 112 (4 waves) on its
+// own; the log-focal pinhole sweep is held to 80 (6 waves); its general-focal instantiation would spill at 80 and keeps its own
+// 96, and so do its scratch-plane instantiations SLAT != 0 (never the library's built-in choice for pinhole)
 template <int MODEL, bool HAS_UP, bool HAS_UPC, bool HAS_LATC, bool LOGF, int VEC, int SLAT = 0>
 __global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL == GCLM_RADIAL) ? GCLM_RADIAL_WAVES : (VEC == 4 && MODEL > GCLM_RADIAL) ? GCLM_DIV_WAVES : (VEC == 4 && MODEL == GCLM_SIMPLE_RADIAL) ? 4 : (VEC == 4 && MODEL == GCLM_PINHOLE && LOGF) ? (SLAT == 0 ? GCLM_PINHOLE_WAVES : 5) : GCLM_MIN_WAVES) void sweep_kernel(
     const SweepArgs a) {
     if (stop_fired_before(a.ctrl, a.stop_step)) return;   // batch-global early stop, no host sync
-#if GCLM_XCD_REMAP      // A/B switch: each XCD (block id % 8) walks a contiguous eighth of the batch
-    int b = blockIdx.y, chunk = blockIdx.x;
-    {
-        const unsigned total = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
-        if ((total & 7u) == 0) {
-            const unsigned nid = (lin & 7u) * (total >> 3) + (lin >> 3);
-            b = (int)(nid / gridDim.x);
-            chunk = (int)(nid - (unsigned)b * gridDim.x);
-        }
-    }
-#elif GCLM_ORDER == 1   // A/B switch (placement probe): consecutive workgroups take the SAME chunk of consecutive images
-    const unsigned lin1 = blockIdx.y * gridDim.x + blockIdx.x;
-    const int chunk = (int)(lin1 / gridDim.y), b = (int)(lin1 - (unsigned)chunk * gridDim.y);
-#elif GCLM_ORDER == 2   // ... images visited with a stride of 389 (coprime to the batch sizes probed)
-    const int chunk = blockIdx.x, b = (int)((blockIdx.y * 389u) % gridDim.y);
-#elif GCLM_ORDER == 3   // ... two windows half a batch apart
-    const int chunk = blockIdx.x, b = (int)((blockIdx.y & 1u) ? (gridDim.y + 1) / 2 + blockIdx.y / 2 : blockIdx.y / 2);
-#else
     const int b = blockIdx.y, chunk = blockIdx.x;
-#endif
     const PBlock P = a.pb[b];                            // workgroup-uniform -> scalar loads
     sweep_body<MODEL, HAS_UP, HAS_UPC, HAS_LATC, LOGF, VEC, 0, SLAT>(a, P, b, chunk);
 }
@@ -1440,7 +1219,7 @@ hipError_t dispatch(const SweepArgs& a, hipStream_t s) {
     const dim3 grid(a.nchunks, a.B), block(kBlock);
     const bool up = a.up != nullptr, upc = up && a.upc != nullptr, latc = a.latc != nullptr;
     // the log-focal specialisation only for the vector path (the scalar path is the odd-shape fallback)
-    const bool logf = VEC == 4 && a.log_focal != 0 && GCLM_LOGF;
+    const bool logf = VEC == 4 && a.log_focal != 0;
 #define GCLM_LAUNCH(U, UC, LC)                                                                          \
     do {                                                                                                \
         if (logf) hipLaunchKernelGGL((sweep_kernel<MODEL, U, UC, LC, VEC == 4, VEC>), grid, block, 0, s, a); \
@@ -1476,7 +1255,7 @@ template <int MODEL>
 hipError_t dispatch_fused(const SweepArgs& a, const FusedArgs& f, hipStream_t s) {
     const dim3 grid(a.nchunks, a.B), block(kBlock);
     const bool up = a.up != nullptr, upc = up && a.upc != nullptr, latc = a.latc != nullptr;
-    const bool logf = a.log_focal != 0 && GCLM_LOGF;
+    const bool logf = a.log_focal != 0;
 #define GCLM_LAUNCH(U, UC, LC)                                                                               \
     do {                                                                                                     \
         if (logf) hipLaunchKernelGGL((fused_step_kernel<MODEL, U, UC, LC, true>), grid, block, 0, s, a, f);  \
@@ -1509,8 +1288,6 @@ hipError_t launch_sweep(int camera_model, const SweepArgs& a, hipStream_t s) {
         default: return hipErrorInvalidValue;
     }
 }
-
-bool sweep_has_log_focal() { return GCLM_LOGF != 0; }
 
 bool sweep_has_slat_plane(int camera_model) {
     return camera_model > GCLM_PINHOLE ? camera_model <= GCLM_SIMPLE_DIVISIONAL : (camera_model == GCLM_PINHOLE && GCLM_SLAT_PINHOLE != 0);
