@@ -30,14 +30,18 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$NAME -o pmc --
 echo "== pmc WRITE_SIZE"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$NAME -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --repeats 1 --cpu-sample 0 --no-timing --no-secondary --no-overlap --camera-model $MODEL $EXTRA > $OUT/pmc_write_$NAME.log 2>&1
 python - <<PY
-import csv, glob, json, collections
+import csv, glob, json, collections, re
 out = {}
 for name in ("fetch", "write"):
     files = glob.glob("$OUT/pmc_%s_$NAME/**/*counter_collection.csv" % name, recursive=True)
     agg = collections.defaultdict(list)
     for f in files:
         for row in csv.DictReader(open(f)):
-            agg[(row.get("Kernel_Name", "")[:60], row.get("Counter_Name"))].append(float(row.get("Counter_Value", 0)))
+            # keyed by the kernel WITH its full template argument list: sweep_kernel<1, ..., 4, 1> (the first sweep of a
+            # simple_radial solve, which also writes the scratch plane) and <..., 2> (every later sweep) are different rows
+            kn = row.get("Kernel_Name", "")
+            m = re.search(r"(\w+_kernel<[^>]*>)", kn)
+            agg[(m.group(1) if m else kn[:120], row.get("Counter_Name"))].append(float(row.get("Counter_Value", 0)))
     for (k, c), v in sorted(agg.items()):
         if "sweep" in k:
             out["%s:%s" % (c, k)] = {"n": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)}

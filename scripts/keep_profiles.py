@@ -41,12 +41,26 @@ for f in sorted(glob.glob(os.path.join(src, "pmc_summary_*.json"))):
     s = json.load(open(f))
     if any(k.startswith("FETCH_SIZE") for k in s) and any(k.startswith("WRITE_SIZE") for k in s) and "_B" in name:
         model, b = name.rsplit("_B", 1)
-        # the loop sweeps dominate (20 of 21 launches); mean over all sweep instantiations, weighted by their launch counts
+        # per instantiation (FETCH_SIZE x 2 + WRITE_SIZE, KB -> bytes), and per SOLVE: the launch-weighted mean over all sweep
+        # instantiations of the run (20 loop sweeps + 1 final sweep; simple_radial: 1 plane-writing + 20 plane-reading)
+        inst = {}
+        for k, v in s.items():
+            counter, kern = k.split(":", 1)
+            inst.setdefault(kern, {})[counter] = v
+        per = {}
+        for kern, c in inst.items():
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                per[kern] = {"hbm_bytes_per_launch": int(round((2 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024)),
+                             "fetch_size_kb": c["FETCH_SIZE"]["mean"], "write_size_kb": c["WRITE_SIZE"]["mean"],
+                             "launches_fetch_pass": c["FETCH_SIZE"]["n"], "launches_write_pass": c["WRITE_SIZE"]["n"]}
         fs = [(v["mean"], v["n"]) for k, v in s.items() if k.startswith("FETCH_SIZE")]
         ws = [(v["mean"], v["n"]) for k, v in s.items() if k.startswith("WRITE_SIZE")]
         fm = sum(a * n for a, n in fs) / sum(n for _, n in fs)
         wm = sum(a * n for a, n in ws) / sum(n for _, n in ws)
         traffic[f"{model}_B{b}_640x480"] = {"hbm_bytes_per_launch": int(round((2 * fm + wm) * 1024)), "fetch_size_kb": fm, "write_size_kb": wm,
+                                              "what": "mean over ALL sweep launches of the solves under the counters (per-solve figure); "
+                                                      "`per_instantiation` splits it by template arguments",
+                                              "per_instantiation": per,
                                               "correction": "FETCH_SIZE x 2 on gfx950 for 16 B/lane streaming reads (MI355X_MICROARCH.md, HBM)", "source": f"profiles/{tag}_pmc_hbm_{name}.json"}
 json.dump(traffic, open(tpath, "w"), indent=1)
 print("\n".join(kept))

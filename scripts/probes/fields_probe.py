@@ -27,6 +27,14 @@ for B, H, W in ((256, 480, 640), (1024, 480, 640), (1, 480, 640)):
     byt = B * H * W * 4 * 10
     rows.append({"kernel": "gclm_pack_fields (in place)", "B": B, "H": H, "W": W, "ms": round(ms, 4), "GB/s": round(byt / ms / 1e6, 1), "bytes": byt})
     print(rows[-1], flush=True)
+    # the read + write streaming ceiling of the SAME four tensors in this process: x *= 1.0 in place (torch's vectorised
+    # elementwise kernel, 4 launches; `one` is a device scalar, nothing to fold).  scripts/probes/pack_bench.hip holds the
+    # hand-written copy with pack_fields' own launch shape (round 5's copy baseline had been optimised away)
+    one = torch.ones((), device=dev)
+    ms_c = timeit(lambda: (up_raw.mul_(one), lat_raw.mul_(one), ulc.mul_(one), llc.mul_(one)))
+    rows.append({"kernel": "torch x *= 1.0 in place on the same tensors (read + write ceiling, 4 launches)", "B": B, "H": H, "W": W,
+                 "ms": round(ms_c, 4), "GB/s": round(byt / ms_c / 1e6, 1), "bytes": byt})
+    print(rows[-1], flush=True)
     # eager torch epilogue (what the reference's heads run), for scale
     def eager():
         u = torch.nn.functional.normalize(up_raw, dim=1); c1 = torch.sigmoid(ulc)
@@ -55,4 +63,18 @@ for B, (h, w), (H, W) in ((256, (240, 320), (480, 640)), (64, (320, 480), (1080,
 if "--json" in sys.argv:
     out = sys.argv[sys.argv.index("--json") + 1]
     os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
-    json.dump({"what": "kernels either side of the LM path; GB/s = algorithmic bytes (read + written once) / mean time over 20 calls (torch events; upsample includes its output allocation)", "rows": rows}, open(out, "w"), indent=1)
+    extra = {}
+    log = os.path.join(os.path.dirname(os.path.abspath(out)), "pack_bench.log")      # written by scripts/r06_collect.sh just before
+    if os.path.exists(log):
+        import re
+        cur = None
+        for ln in open(log):
+            m = re.match(r"== B = (\d+)", ln)
+            if m:
+                cur = f"B{m.group(1)}"
+            m = re.match(r"\s+(copy[^=]*?|nt both, grid 300 \(one pass\))\s+mean\s+([\d.]+) us .*= +([\d.]+) TB/s", ln)
+            if m and cur:
+                extra.setdefault(cur, {})[m.group(1).strip()] = {"mean_us": float(m.group(2)), "TB/s": float(m.group(3)), "frac_of_8": round(float(m.group(3)) / 8, 4)}
+    json.dump({"pack_fields_read_write_ceiling": {"source": "scripts/probes/pack_bench.hip (same call): in-place copy x * 1.0f of the five planes with "
+               "pack_fields' launch shape (grid 300 x B, one pass) vs the epilogue's arithmetic on the same shape", "rows": extra},
+               "what": "kernels either side of the LM path; GB/s = algorithmic bytes (read + written once) / mean time over 20 calls (torch events; upsample includes its output allocation)", "rows": rows}, open(out, "w"), indent=1)
