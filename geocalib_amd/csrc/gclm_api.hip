@@ -21,7 +21,7 @@ using namespace gclm;
 
 #ifndef GCLM_FUSED_MAX_WORKGROUPS
 #define GCLM_FUSED_MAX_WORKGROUPS 768      // B * workgroups-per-image up to which an LM step is ONE launch (see use_fused):
-                                           // measured with round 4's prologue (profiles/r04_fused_threshold.log, 20 fixed steps) --
+                                           // measured with round 4's prologue (profiles/archive/r04_fused_threshold.log, 20 fixed steps) --
                                            // 640x480 (150 workgroups per image): B = 2 -19 %, 4 -15 %, 6 +-0, 8 +6 %, 12 +15 %;
                                            // 320x240 (38 per image): B = 2 ... 12 -20 ... -27 %
 #endif
@@ -333,7 +333,7 @@ Geometry plan_geometry(int B, int H, int W, bool aligned16, int sweep_iters, int
     // fill 256 CUs x 4+ workgroups.
     // The distortion models are VALU-bound: their per-workgroup prologue / epilogue is worth amortising over
     // 30 iterations where the image divides into whole blocks of that many rows (640x480: 8 blocks of 60 rows; same-allocation
-    // A/B profiles/r04_variant_huber_clamp.log: simple_radial -0.3 %, radial -1.2 %, simple_divisional -0.7 %, pinhole +0.4 %).
+    // A/B profiles/archive/r04_variant_huber_clamp.log: simple_radial -0.3 %, radial -1.2 %, simple_divisional -0.7 %, pinhole +0.4 %).
     int builtin = 20;
     if (camera_model != GCLM_PINHOLE && H % (g.rpi * 30) == 0) builtin = 30;
     int iters = (sweep_iters >= 1 && sweep_iters <= 4096) ? sweep_iters : builtin;   // gclm_set_sweep_iters (tuning / tests)

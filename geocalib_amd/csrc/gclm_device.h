@@ -381,7 +381,7 @@ constexpr int kGroups = 8, kSlots = 32, kStripeMinChunks = 33;
 // records, so the reduction does not wait for them (loads return in order).
 // The sums are valid in the threads of WAVE 0 on return (lane i of wave 0 sums slot i over the stripes, v_readlane hands
 // the values to the whole wave): round 3 had every one of the 256 threads read all 8 x 24 doubles back from LDS -- 1 us of
-// LDS bandwidth at the head of every launch of a single-image solve (device trace, profiles/r04_latency_trace.log).
+// LDS bandwidth at the head of every launch of a single-image solve (device trace, profiles/archive/r04_latency_trace.log).
 template <typename Hook>
 __device__ inline void reduce_image_partials(const float* image_partials, int nchunks, int nacc, float (&acc)[kNAccMax],
                                              Hook&& after_first_batch) {

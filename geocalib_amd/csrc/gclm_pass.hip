@@ -948,7 +948,7 @@ __global__ __launch_bounds__(kBlock) void fused_step_kernel(const SweepArgs a, c
         if (!f.is_final) {
             // every launch after the one that detected the stop leaves its counter at 0 too (see Ctrl).  (Testing the counter
             // only after the partial records have been requested as well -- one round trip instead of two -- was measured: the
-            // active launches gain nothing, the skipped ones cost 3.0 instead of 2.3 us each; profiles/r04_latency_trace.log.)
+            // active launches gain nothing, the skipped ones cost 3.0 instead of 2.3 us each; profiles/archive/r04_latency_trace.log.)
             if (step >= 3 && c.ctrl->notclose[step - 2] == 0) return;
         } else {
             // the first counter in [1, step - 2] that stayed 0: all of them in one round trip, 64 per wave-load

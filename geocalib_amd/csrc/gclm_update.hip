@@ -594,7 +594,7 @@ __global__ void pack_fields_kernel(const float* __restrict__ up_raw, const float
             float vx[VEC], vy[VEC], vl[VEC], c1[VEC], c2[VEC];
             if constexpr (VEC == 4) {
                 // every byte is read once and written once: non-temporal both ways (+4 ... 8 % over plain float4 accesses,
-                // profiles/r05_pack_bench.log)
+                // profiles/archive/r05_pack_bench.log)
                 typedef float pk4 __attribute__((ext_vector_type(4)));
                 auto ld4 = [](const float* p, size_t j) { return __builtin_nontemporal_load(reinterpret_cast<const pk4*>(p) + j); };
                 const pk4 a = ld4(ux, i), bq = ld4(uy, i), l = ld4(lat_raw + (size_t)b * N, i);
@@ -678,7 +678,7 @@ __device__ __forceinline__ void upsample_plane(const float* __restrict__ s, floa
 //   * Position q of a row maps to unit (q + o) mod Wu, o = the units from the row's first byte up to the next 128-byte
 //     line: every full wave store then starts on a line.  Rows of 1620 floats (6480 B) are not whole lines; round 4
 //     wrote each wave's 1 KiB across nine lines, two of them partial, and the stores alone took 1.75x a flat fill
-//     (profiles/r05_upsample_bench.log: 652 -> 439 us for 64 x 5 planes 320x480 -> 1080x1620).
+//     (profiles/archive/r05_upsample_bench.log: 652 -> 439 us for 64 x 5 planes 320x480 -> 1080x1620).
 //   * CONSEC (rows are whole 64-byte half lines, Wu % 4 == 0): a wave walks ROWS consecutive output rows; every source
 //     row it needs is loaded up front (RMAX, when the vertical ratio bounds their number) and its horizontally interpolated
 //     values stay in registers for all output rows that tap it.  The (up to four) waves of a block take adjacent strips
@@ -911,7 +911,7 @@ __global__ __launch_bounds__(KIND == kUpPhased ? 512 : 256) void upsample_kernel
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         // CONSEC: the waves of a block take ADJACENT strips of the same ROWS rows -- a block writes whole rows (of up to
         // 1024 px), row after row, instead of four row groups of one strip: 0.346 -> 0.323 ms on the x2 case
-        // (profiles/r05_upsample_bench.log, "rowblock").  The other kinds: blockIdx.x = strip, waves = row groups / phases.
+        // (profiles/archive/r05_upsample_bench.log, "rowblock").  The other kinds: blockIdx.x = strip, waves = row groups / phases.
         // (one image: the old grouping, four row groups of one strip per block -- 4.5 against 5.5 us for 5 planes of 480x640)
         const bool rb = KIND == kUpConsec && rowblock != 0;
         const int strip = rb ? blockIdx.x * 4 + wave : blockIdx.x;

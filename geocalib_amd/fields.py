@@ -130,7 +130,7 @@ def fastest_placement(allocate, solve, tries: int = 3, keep_first: bool = False)
 
     Round 4 tried to control the placement instead of choosing it (HIP virtual-memory management: one physical handle per
     batch / per tensor / per 2 MiB .. 1 GiB chunk, 1 GiB-aligned tensors): same spread, same discrete levels
-    (profiles/r04_vmm_placement.log) -- choosing among allocations stays the only handle a caller has."""
+    (profiles/archive/r04_vmm_placement.log) -- choosing among allocations stays the only handle a caller has."""
     if tries <= 1:
         f = allocate()
         return (f, [], f) if keep_first else (f, [])

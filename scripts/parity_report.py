@@ -1,7 +1,7 @@
 """Per-model worst-case table of what the GPU parity suite MEASURED (build container or GPU box).
 
     GCLM_PARITY_LOG=gpurun_out/r03/parity_measured.json python -m pytest tests -m gpu      # on the GPU box
-    python scripts/parity_report.py gpurun_out/r03/parity_measured.json [gpurun_out/fuzz_measured_*.json ...] --json profiles/r03_parity.json
+    python scripts/parity_report.py gpurun_out/r03/parity_measured.json [gpurun_out/fuzz_measured_*.json ...] --json profiles/archive/r03_parity.json
 
 tests/conftest.compare_result (and the fuzz) record every distance they gate: focal (relative), distortion / gravity
 (absolute), costs / covariance / uncertainties (relative to the largest entry).  This script groups the records by camera

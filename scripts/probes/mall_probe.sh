@@ -2,7 +2,7 @@
 # GPU box: does a batch that fits the 256 MiB Infinity Cache sweep faster than HBM allows?  Builds the sweep with and
 # without non-temporal loads (and the no-math variant of each = the memory system alone) and times it at batch sizes
 # either side of the cache's capacity (6.1 MB per 640x480 image: 32 images = 197 MB).  Leaves the DEFAULT build in place.
-# CLOSED (round 3, profiles/r03_mall_probe.log): the -DGCLM_NT_LOADS=0 switch left gclm_pass.hip in round 6 -- the sweep's loads are
+# CLOSED (round 3, profiles/archive/r03_mall_probe.log): the -DGCLM_NT_LOADS=0 switch left gclm_pass.hip in round 6 -- the sweep's loads are
 # always non-temporal; check out a round-5 tree to re-run the plain-load half of this probe.
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out

@@ -3,7 +3,7 @@
     python scripts/probes/vmm_probe.py [--maps 10] [--model pinhole] [--batch 1024]
 
 The memory-bound pinhole sweep runs 928 ... 1005 us on the same 6.3 GB depending on which physical pages back the four
-input tensors (profiles/r03_placement_probe2.log); virtual layout and padding do not explain it.  Here the five planes
+input tensors (profiles/archive/r03_placement_probe2.log); virtual layout and padding do not explain it.  Here the five planes
 of a B=1024 batch are backed by hipMemCreate physical handles mapped with hipMemAddressReserve / hipMemMap:
 
     malloc        control: one hipMalloc per tensor (what torch's allocator does for blocks this large)

@@ -108,7 +108,7 @@ MEASURED = {}      # label -> what compare_result / the fuzz actually measured (
 
 
 def measure_result(out: dict, ref: dict) -> dict:
-    """The distances compare_result gates, as numbers (scripts/parity_report.py, profiles/r03_parity.json)."""
+    """The distances compare_result gates, as numbers (scripts/parity_report.py, profiles/archive/r03_parity.json)."""
     def rel(a, b):
         return float(np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
     cam, rcam = np.asarray(out["camera"]), ref["camera"]

@@ -117,7 +117,7 @@ def test_hip_matches_reference_full_size_other_models(dev, model, idx):
 
 
 # BASELINE configs[0] restated on the fields of a RANDOM-INIT CNN: north_star's 1e-4 without exception (round 2 allowed
-# 2e-3 on the focal for this ill-conditioned problem; measured: 6e-8, profiles/r03_parity.json).  No distortion: exact.
+# 2e-3 on the focal for this ill-conditioned problem; measured: 6e-8, profiles/archive/r03_parity.json).  No distortion: exact.
 TOL_CNN = {**TOL, "dist": 1e-6}
 
 
@@ -927,7 +927,7 @@ def test_randomised_configurations_against_oracle(dev, oracle):
     confidences / up field, priors and scales -- the HIP path against the oracle on identical inputs, and for
     `simple_divisional` against the REFERENCE's own result on that draw (tests/golden/make_golden_div.py: seeds 2024 and
     11..22), gated by the yardstick's own reproducibility.  GCLM_FUZZ_SEED / GCLM_FUZZ_CASES: the soak
-    (scripts/fuzz_soak.sh -> profiles/r03_fuzz_soak.txt)."""
+    (scripts/fuzz_soak.sh -> profiles/archive/r03_fuzz_soak.txt)."""
     from conftest import MEASURED, fuzz_draws, perturbed, result_spread
     seed = int(os.environ.get("GCLM_FUZZ_SEED", "2024"))                             # soak: GCLM_FUZZ_CASES=300
     n_cases, n_models = int(os.environ.get("GCLM_FUZZ_CASES", "80")), int(os.environ.get("GCLM_FUZZ_MODELS", "4"))
