@@ -384,7 +384,27 @@ class LMOptimizer(nn.Module):
         with torch.no_grad():
             data["latitude_field"]            # KeyError like get_trivial_estimation (lm_optimizer.py:31)
             self.setup_optimization_and_priors(data, shared_intrinsics=self.shared_intrinsics)
+            if self.conf.verbose:
+                return self._forward_verbose(data)
             camera_opt, gravity_opt, infos = self.calibrate_fields(data)
+        return {"camera": camera_opt, "gravity": gravity_opt, **infos}
+
+    def _forward_verbose(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """conf.verbose (lm_optimizer.py:652-662): the reference's five log lines.  Its timing is a host wall clock around
+        synchronous tensor ops; the solve here is asynchronous, so the verbose path (only) synchronises the device around it."""
+        import time
+        from .utils import rad2deg
+        device = data["latitude_field"].device
+        camera_init, gravity_init = get_trivial_estimation(data, self.camera_model)
+        torch.cuda.synchronize(device)
+        start = time.time()
+        camera_opt, gravity_opt, infos = self.calibrate_fields(data)
+        torch.cuda.synchronize(device)
+        logger.info(f"Optimization took {(time.time() - start) * 1000:.2f} ms")
+        logger.info(f"Initial camera:\n{rad2deg(camera_init.vfov)}")
+        logger.info(f"Optimized camera:\n{rad2deg(camera_opt.vfov)}")
+        logger.info(f"Initial gravity:\n{rad2deg(gravity_init.rp)}")
+        logger.info(f"Optimized gravity:\n{rad2deg(gravity_opt.rp)}")
         return {"camera": camera_opt, "gravity": gravity_opt, **infos}
 
     _MAX_CALL = 65535      # images per C call (grid.y of the sweep)

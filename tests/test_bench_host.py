@@ -95,3 +95,43 @@ def test_cpu_baseline_survives_a_broken_reference_checkout(monkeypatch, tmp_path
             del sys.modules[k]
         sys.modules.update(saved)
     assert out["kind"] == "port" and out["reference_on_this_box"] is False and "reference_error" in out
+
+
+def test_vs_oracle_record_and_the_kept_oracle_result(monkeypatch):
+    """`check.vs_oracle`: cpu_baseline hands the oracle's solve of the sample back (`keep`), vs_oracle turns
+    it and the HIP rows into the record of the bench line -- distances next to the 1e-4 gate; a NaN is never inside a gate;
+    shared-intrinsics samples are solved group by group like the reference does."""
+    import numpy as np
+    bench = _bench()
+    from oracle import ref_import
+    monkeypatch.setattr(ref_import, "REFERENCE_ROOT", "/nonexistent/reference")
+    data = _sample(6)
+    kept = {}
+    out = bench.cpu_baseline(_args(), 6, data, keep=kept)
+    assert out["kind"] == "port" and set(kept) == {"camera", "gravity", "final_cost"}
+    assert kept["camera"].shape == (6, 8) and kept["gravity"].shape == (6, 3) and kept["final_cost"].shape == (6,)
+    same = bench.vs_oracle({k: v.copy() for k, v in kept.items()}, kept, "itself")
+    assert same["within_gate"] is True and same["images"] == 6 and same["gate"] == 1e-4
+    assert same["max_focal_rel"] == same["max_gravity_abs"] == same["max_final_cost_rel"] == 0.0
+    off = {k: v.copy() for k, v in kept.items()}
+    off["camera"][2, 3] *= 1 + 3e-4
+    rec = bench.vs_oracle(off, kept, "a focal 3e-4 off")
+    assert rec["within_gate"] is False and 2.9e-4 < rec["max_focal_rel"] < 3.1e-4 and "a focal 3e-4 off" in rec["against"]
+    nan = {k: v.copy() for k, v in kept.items()}
+    nan["gravity"][0, 0] = np.nan
+    assert bench.vs_oracle(nan, kept, "nan")["within_gate"] is False
+    # more HIP rows than oracle rows: only the sample is compared
+    more = {k: np.concatenate([v, v]) for k, v in kept.items()}
+    assert bench.vs_oracle(more, kept, "prefix")["images"] == 6
+    # shared intrinsics: one oracle call per group of `group` frames (lm_optimizer.py:350-383), concatenated in order
+    args = _args()
+    args.shared_group = 3
+    kept_g = {}
+    out_g = bench.cpu_baseline(args, 6, data, keep=kept_g)
+    assert out_g["unit"] == "frames/sec" and "2 shared-intrinsics groups of 3" in out_g["sample"]
+    assert kept_g["camera"].shape == (6, 8)
+    for lo in (0, 3):
+        assert np.ptp(kept_g["camera"][lo:lo + 3, 3]) == 0            # one focal per group ...
+    assert kept_g["camera"][0, 3] != kept_g["camera"][3, 3]          # ... and not the same for both
+    direct = bench.oracle_solve("pinhole", 5, {k: v[:3] for k, v in data.items()}, 3, 2)
+    assert np.array_equal(direct["camera"], kept_g["camera"][:3])

@@ -269,6 +269,21 @@ def test_training_mode_skips_uncertainty(dev):
     assert np.abs(out["camera"][:, 2:4] / small["pinhole/training/camera"][:, 2:4] - 1).max() < 1e-4
 
 
+def test_verbose_conf_logs_the_reference_lines(dev, caplog):
+    """conf.verbose (lm_optimizer.py:652-662): five log lines -- the time, initial / optimised vfov and roll-pitch in degrees --
+    and the same result as the quiet solve, bit for bit."""
+    import logging
+    from geocalib_amd import LMOptimizer
+    data = to_dev(data_for("pinhole", "default"), dev)
+    quiet = to_np(LMOptimizer(conf_for("pinhole", "default")).eval()(dict(data)))
+    with caplog.at_level(logging.INFO, logger="geocalib_amd.lm_optimizer"):
+        loud = to_np(LMOptimizer({**conf_for("pinhole", "default"), "verbose": True}).eval()(dict(data)))
+    msgs = [r.getMessage() for r in caplog.records]
+    assert len(msgs) == 5 and msgs[0].startswith("Optimization took") and msgs[0].endswith("ms")
+    assert [m.split(":")[0] for m in msgs[1:]] == ["Initial camera", "Optimized camera", "Initial gravity", "Optimized gravity"]
+    assert all(np.array_equal(quiet[k], loud[k], equal_nan=True) for k in quiet)
+
+
 def test_reference_error_behaviour(dev):
     from geocalib_amd import LMOptimizer, _lib
     lat = torch.zeros(2, 1, 16, 16, device=dev)
