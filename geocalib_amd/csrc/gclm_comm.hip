@@ -139,13 +139,21 @@ int gclm_comm_create(gclm_comm** out, const void* unique_id, int nranks, int ran
                         std::to_string(NCCL_VERSION_CODE) + " (major versions differ)";
         return cfail(nullptr, -21, "gclm_comm_create", m.c_str());
     }
+    // ncclCommInitRank binds the communicator to the CURRENT device: switch to `device` for the call and hand the caller's
+    // current device back afterwards, like every handle-taking entry point does (include/gclm.h)
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (hipSetDevice(device) != hipSuccess) return cfail(nullptr, -10, "gclm_comm_create", "hipSetDevice failed");
     gclm_comm* c = new (std::nothrow) gclm_comm();
-    if (!c) return cfail(nullptr, -12, "gclm_comm_create", "out of host memory");
+    if (!c) {
+        if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+        return cfail(nullptr, -12, "gclm_comm_create", "out of host memory");
+    }
     c->nranks = nranks; c->rank = rank; c->device = device;
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof(id));
     ncclResult_t r = L.CommInitRank(&c->comm, nranks, id, rank);
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
     if (r != ncclSuccess) {
         cfail(nullptr, -20, "ncclCommInitRank", L.GetErrorString(r));
         delete c;
