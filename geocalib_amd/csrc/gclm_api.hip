@@ -186,16 +186,19 @@ void ensure_slat(gclm_handle* h, size_t floats) {
     if (bytes <= h->slat_bytes) { h->slat = h->slat_buf; return; }
     if (h->slat_refused && bytes >= h->slat_refused) return;
     if (h->slat_limit && bytes > h->slat_limit) { h->slat_refused = bytes; return; }     // (the old, smaller plane stays)
+    if (!h->slat_limit) {                     // built-in rule: half of what is free once the old plane is released
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > (free_b + h->slat_bytes) / 2) {
+            (void)hipGetLastError();
+            h->slat_refused = bytes;          // (the old, smaller plane stays here too)
+            return;
+        }
+    }
     if (h->slat_buf) (void)hipFree(h->slat_buf);
     h->slat_buf = nullptr;
     h->slat_bytes = 0;
-    bool ok = true;
-    if (!h->slat_limit) {
-        size_t free_b = 0, total_b = 0;
-        ok = hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes <= free_b / 2;
-    }
     void* p = nullptr;
-    if (ok) ok = hipMalloc(&p, bytes) == hipSuccess && p != nullptr;
+    const bool ok = hipMalloc(&p, bytes) == hipSuccess && p != nullptr;
     if (!ok) {
         (void)hipGetLastError();          // the failure is handled here: it must not surface in the next launch's status
         h->slat_refused = bytes;
