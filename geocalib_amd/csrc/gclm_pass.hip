@@ -228,8 +228,12 @@ __device__ __forceinline__ void radial_terms(const PBlock& P, F r2, Radial<F>& R
         // the correctly rounded one's accuracy for three packed operations (+ two for 1 / t1).  The reciprocal is stepped to the
         // SAME point: the Jacobian terms below are cancelling sums of t1 and 1 / t1, and a root and a reciprocal that belong to
         // two points a few 1e-8 apart break those cancellations where the terms are large (fuzz 29/162; profiles/README.md).
+        // Ties: for t0 = 1 - 2^-24 (4 k r2 within an ulp of 1: the pixels next to the principal point while |k| ~ 6e-8 f^2) the
+        // Newton estimate is EXACTLY the midpoint of two floats and round-to-even picks 1.0, where the true root (always
+        // below Newton's estimate) rounds to 1 - 2^-24 as torch.sqrt does: 1 - t1 = 0 instead of 2^-24 made the up vector of those
+        // pixels and their k-derivative garbage 40x the reference's own (fuzz 101/270).  A nudge of 2^-21 half-ulps breaks it.
         const F t1h = vsqrt_hw(t0), ih = vrcp_hw(t1h);
-        const F t1 = vfma(vfma(-t1h, t1h, t0), 0.5f * ih, t1h);
+        const F t1 = vfma(vfma(t0, vsplat(t0, -0x1p-45f), vfma(-t1h, t1h, t0)), 0.5f * ih, t1h);
         const F it1 = vfma(ih, vfma(-t1, ih, one), ih), it0 = it1 * it1;
         const F ssq = vsel_eq0(t0 - tt, t1, vsqrt_hw(vmax(tt, zero)));      // tt < 1e-6 (|4 k r2| ~ 1): nothing cancels there
         const F ir2 = vrcp_hw(r2), ir4 = ir2 * ir2, ir6 = ir4 * ir2;    // inf for r2 = 0: only read behind the selects
