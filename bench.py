@@ -29,7 +29,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
   secondary:    N=1 default run only: BASELINE configs[3] (simple_radial, B=1024) and configs[4]'s shape (shared intrinsics,
                 64 groups x 16 frames) at 5 steps after 2 warm-ups each, same event-based sweep timing, ground-truth check and
                 `check.vs_oracle` (64 images each); configs[3] also carries `slat_off`: the same solves on the same allocation
-                with the sin(latitude) scratch plane switched off (gclm_set_slat_plane(h, 0)) -- the plane's effect on THIS box.
+                with the sin(latitude) scratch plane switched off (gclm_set_slat_plane(h, 0)) -- the plane's effect on THIS box;
+                and SURVEY 8(f)1's simple_divisional at B=1024 with `row_pairs_off`: the same solves with the one-row walk of the
+                sweep (gclm_set_row_pairs(h, 0)) -- the row-pair walk's effect on THIS box.
   overlap:      N=1, independent intrinsics: the same batch solved as two halves on two side streams
                 (LMOptimizer.overlap_streams = 2, the library's default for large batches); `value` stays the one-stream run.
 The timed region (exactly --steps steps between barrier + synchronize) is run --repeats times; `value` and
@@ -115,12 +117,16 @@ def vs_oracle(hip, ref, what):
     camera (n,8), gravity (n,3), final_cost (n,)."""
     import numpy as np
     n = ref["camera"].shape[0]
-    f = float(np.abs(hip["camera"][:n, 2:4] / ref["camera"][:, 2:4] - 1).max())
-    g = float(np.abs(hip["gravity"][:n] - ref["gravity"]).max())
-    c = float(np.abs(hip["final_cost"][:n] / ref["final_cost"] - 1).max())
+    fi = np.abs(hip["camera"][:n, 2:4] / ref["camera"][:, 2:4] - 1).max(1)           # per image
+    gi = np.abs(hip["gravity"][:n] - ref["gravity"]).max(1)
+    ci = np.abs(hip["final_cost"][:n] / ref["final_cost"] - 1)
+    f, g, c = float(fi.max()), float(gi.max()), float(ci.max())
     d = [x for x in (f, g, c)]
+    ok = (fi <= ORACLE_GATE) & (gi <= ORACLE_GATE) & (ci <= ORACLE_GATE)             # (a NaN compares false)
     return {"images": int(n), "max_focal_rel": f, "max_gravity_abs": g, "max_final_cost_rel": c, "gate": ORACLE_GATE,
             "within_gate": bool(all(x == x and x <= ORACLE_GATE for x in d)),        # (x == x: a NaN is not within any gate)
+            "images_within_gate": int(ok.sum()), "median_focal_rel": float(np.median(fi)), "median_gravity_abs": float(np.median(gi)),
+            "median_final_cost_rel": float(np.median(ci)),
             "against": "oracle/lm_oracle.c (float32), " + what}
 
 
@@ -265,11 +271,12 @@ def reference_torch(args):
 
 
 def quick_case(lib, LMOptimizer, synth_fields, dev, model, B, H, W, lm_steps, seed, group, steps=5, warmup=2, oracle_images=64,
-               slat_control=False):
+               slat_control=False, pairs_control=False):
     """One secondary record: `steps` solves after `warmup`, first allocation, one stream; sweep launches timed with the
     library's HIP events, result checked against the synthetic ground truth like the headline and -- the first
     `oracle_images` images -- against the CPU oracle's solve of the same fields.  `slat_control`: the same measurement again
-    with the sin(latitude) scratch plane off, then on again (same allocation, same process: A / B / A)."""
+    with the sin(latitude) scratch plane off, then on again (same allocation, same process: A / B / A).  `pairs_control`: the
+    same for the row-pair walk of the sweep (LMOptimizer.row_pairs = False = gclm_set_row_pairs(h, 0), then the default again)."""
     conf = {"camera_model": model, "num_steps": lm_steps, "early_stop": False}
     if group:
         conf.update(shared_intrinsics=True, group_size=group)
@@ -301,7 +308,8 @@ def quick_case(lib, LMOptimizer, synth_fields, dev, model, B, H, W, lm_steps, se
     assert f_err < 5e-3 and g_err < 5e-3, (model, group, f_err, g_err)
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
     value = B * steps / dt
-    rec = {"workload": (f"BASELINE configs[3]: batch={B}, {model}" if not group else
+    rec = {"workload": ((f"BASELINE configs[3]: batch={B}, {model}" if model == "simple_radial" else
+                         f"SURVEY 8(f)1: batch={B}, {model}") if not group else
                         f"BASELINE configs[4] shape: shared intrinsics, {B // group} groups x {group} frames, {model}") +
                        f", synthetic {W}x{H}, {lm_steps} LM iters + final/uncertainty sweep, early_stop=False",
            "value": round(value, 1), "unit": "images/sec" if not group else "frames/sec", "steps": steps, "warmup": warmup,
@@ -330,6 +338,28 @@ def quick_case(lib, LMOptimizer, synth_fields, dev, model, B, H, W, lm_steps, se
                            "what": "the same solves on the same allocation with gclm_set_slat_plane(h, 0): every sweep evaluates "
                                    "sin(latitude) per pixel instead of loading the library's scratch plane; then the default "
                                    "again (`on_again`).  `value` / `roofline` above are the default (plane on)"}
+    if pairs_control:
+        on_rows = hip_rows(out, B)
+        opt.row_pairs = False
+        out0, dt0, avg0, n0 = measure()
+        off_rows = hip_rows(out0, B)
+        opt.row_pairs = None
+        _, dt2, avg2, _ = measure()
+        import numpy as np
+        d_f = np.abs(on_rows["camera"][:, 2:4] / off_rows["camera"][:, 2:4] - 1).max(1)
+        d_g = np.abs(on_rows["gravity"] - off_rows["gravity"]).max(1)
+        rec["row_pairs_off"] = {"value": round(B * steps / dt0, 1), "ms_per_step": round(dt0 / steps * 1e3, 4),
+                                "frac": round(bytes_per_launch / (avg0 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(avg0, 4),
+                                "launches_timed": n0,
+                                "median_focal_rel_vs_default": float(np.median(d_f)), "median_gravity_abs_vs_default": float(np.median(d_g)),
+                                "on_again": {"value": round(B * steps / dt2, 1), "ms_per_step": round(dt2 / steps * 1e3, 4),
+                                             "frac": round(bytes_per_launch / (avg2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                                "what": "the same solves on the same allocation with gclm_set_row_pairs(h, 0): every lane walks ONE "
+                                        "row per iteration and evaluates the radial terms per pixel; then the default again "
+                                        "(`on_again`).  `value` / `roofline` above are the default (a lane takes row H - y along "
+                                        "with row y and evaluates what depends on r^2 once for both).  Same per-pixel values, "
+                                        "another order of additions: the two walks' results differ by float32 summation order, "
+                                        "amplified by the solve (medians over the batch beside it)"}
     if oracle_images:
         try:
             from oracle.lm_oracle import effective_cpus
@@ -677,6 +707,8 @@ def main():
                                               oracle_images=64 if args.cpu_sample != 0 else 0, slat_control=True),
             "shared16_pinhole": quick_case(lib, LMOptimizer, synth_fields, dev, "pinhole", B, H, W, args.lm_steps, args.seed, 16,
                                            oracle_images=64 if args.cpu_sample != 0 else 0),
+            f"simple_divisional_B{B}": quick_case(lib, LMOptimizer, synth_fields, dev, "simple_divisional", B, H, W, args.lm_steps, args.seed, 0,
+                                                  oracle_images=64 if args.cpu_sample != 0 else 0, pairs_control=True),
         }
 
     def same_bits(a, b):

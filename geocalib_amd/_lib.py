@@ -16,7 +16,7 @@ INFO_STRIDE = 48
 SHARED_PARTIAL_STRIDE = 32
 COMM_ID_BYTES = 128
 MAX_PARAMS = 5
-ABI_VERSION = 600          # GCLM_VERSION of include/gclm.h this binding was written against
+ABI_VERSION = 610          # GCLM_VERSION of include/gclm.h this binding was written against
 INFO = {"stop_at": 0, "initial_up_cost": 1, "initial_latitude_cost": 2, "initial_cost": 3,
         "final_up_cost": 4, "final_latitude_cost": 5, "final_cost": 6, "roll_uncertainty": 7,
         "pitch_uncertainty": 8, "gravity_uncertainty": 9, "focal_uncertainty": 10,
@@ -102,6 +102,7 @@ _SIGNATURES = {
     "gclm_release_workspace": (C.c_int, [_P]),
     "gclm_read_probe": (C.c_int, [C.POINTER(_P), C.c_int, C.c_size_t, _P]),
     "gclm_plan_cut": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gclm_set_row_pairs": (C.c_int, [_P, C.c_int]),
     "gclm_set_fused_steps": (C.c_int, [_P, C.c_int]),
     "gclm_set_paced_launches": (C.c_int, [_P, C.c_int]),
     "gclm_set_timing": (C.c_int, [_P, C.c_int]),

@@ -25,6 +25,9 @@ using namespace gclm;
                                            // 640x480 (150 workgroups per image): B = 2 -19 %, 4 -15 %, 6 +-0, 8 +6 %, 12 +15 %;
                                            // 320x240 (38 per image): B = 2 ... 12 -20 ... -27 %
 #endif
+#ifndef GCLM_ROW_PAIRS_DEFAULT
+#define GCLM_ROW_PAIRS_DEFAULT -1   // a handle's initial gclm_set_row_pairs mode (1: test builds that run the whole suite on row pairs)
+#endif
 #ifndef GCLM_ISO_FINAL
 #define GCLM_ISO_FINAL 1      // A/B switch: 0 = the final sweep always takes the general focal column
 #endif
@@ -56,6 +59,7 @@ struct gclm_handle {
     size_t slat_limit = 0;          // gclm_set_slat_plane_limit: 0 = built-in rule (half of the free device memory), else bytes
     float* slat = nullptr;          // the plane of the CURRENT solve / session (== slat_buf), or null: sweeps compute sin(latitude)
     int slat_plane = -1;            // gclm_set_slat_plane: -1 = built-in choice, 0 = never, 1 = wherever the sweep has it
+    int row_pairs = GCLM_ROW_PAIRS_DEFAULT;   // gclm_set_row_pairs: -1 = built-in choice, 0 = never, 1 = wherever the sweep has the row-pair walk
     int sweep_iters = 0;            // gclm_set_sweep_iters: 0 = built-in choice
     int fused_mode = -1;            // gclm_set_fused_steps: -1 = built-in choice, 0 = never, 1 = whenever it is valid
     gclm_comm* stop_comm = nullptr; // gclm_set_stop_comm: the batch-global early stop spans the ranks of this communicator
@@ -227,6 +231,30 @@ void apply_slat(const gclm_handle* h, SweepArgs& a, bool& ready) {
     else { a.slat_mode = 1; ready = true; }
 }
 
+// Does a sweep over these planes take the row-pair walk (gclm_pass.hip: row_math_mirror)?  radial / simple_divisional on the
+// five-plane float4 sweep over an even number of rows; never the one-launch-per-step path (its geometry, its prefetch).
+bool mirror_wanted(const gclm_handle* h, bool five_planes, const Geometry& g, int H) {
+    if (h->row_pairs == 0 || g.vec != 4 || !five_planes || (H & 1) || H < 4) return false;
+    return h->row_pairs > 0 ? sweep_has_mirror(h->cfg.camera_model) : sweep_mirror_builtin(h->cfg.camera_model);
+}
+
+bool use_fused(const gclm_handle* h, int B, const Geometry& g);
+
+// The geometry of this call's sweeps: the one-row walk, or -- where the sweep has it and the step is not one launch -- row pairs
+Geometry plan_sweeps(const gclm_handle* h, int B, int H, int W, bool aligned16, bool five_planes) {
+    const Geometry g = plan_geometry(B, H, W, aligned16, h->sweep_iters, h->cfg.camera_model);
+    if (!mirror_wanted(h, five_planes, g, H)) return g;
+    if (h->row_pairs < 0) {
+        // built-in choice: only launches too large for one launch per step, WHETHER OR NOT that path is valid for the call
+        // (early stop over several images, gclm_set_fused_steps(h, 0)): below the threshold a step is latency-bound, and the
+        // two-launch sequence stays the one-launch path's twin bit for bit
+        if ((long long)B * g.nchunks <= GCLM_FUSED_MAX_WORKGROUPS) return g;
+    } else if (h->fused_mode == 1 && use_fused(h, B, g)) {
+        return g;                    // asked for both: the step that can be ONE launch stays one launch
+    }
+    return plan_geometry(B, H, W, aligned16, h->sweep_iters, h->cfg.camera_model, true);
+}
+
 SweepArgs sweep_args(const gclm_handle* h, const float* up, const float* lat, const float* upc, const float* latc,
                      const PBlock* pb, const Geometry& g, bool loop_params, int stop_step) {
     SweepArgs a{};
@@ -235,6 +263,7 @@ SweepArgs sweep_args(const gclm_handle* h, const float* up, const float* lat, co
     a.B = h->ctx.B; a.H = h->ctx.H; a.W = h->ctx.W;
     a.nchunks = g.nchunks; a.vec = g.vec;
     a.wu = g.wu; a.cu = g.cu; a.nstrips = g.nstrips; a.rpi = g.rpi; a.rows_per_block = g.rows_per_block; a.wpt = g.wpt; a.jobs = g.jobs;
+    a.hrows = g.hrows; a.mirror = g.mirror;
     // loop sweeps: the configured parametrisation; final sweep: the (roll, pitch, focal) block, in its log-focal form when
     // every image is known to have fx == fy (iso_final: finalize_kernel rescales the focal column)
     a.log_focal = loop_params ? h->cfg.use_log_focal : h->ctx.iso_final;
@@ -304,9 +333,13 @@ namespace gclm {
 // then for the smallest tile (640 px: 160 units, rpi = 2, 320 lanes = 5 waves, no idle lane).  Wider rows are cut
 // into strips of a multiple of 64 units, one row per iteration.  Every wave of a tile is a job; a workgroup is four
 // consecutive jobs of an image.
-Geometry plan_geometry(int B, int H, int W, bool aligned16, int sweep_iters, int camera_model) {
+Geometry plan_geometry(int B, int H, int W, bool aligned16, int sweep_iters, int camera_model, bool mirror) {
     Geometry g;
     g.vec = (aligned16 && (W % 4 == 0)) ? 4 : 1;
+    // row pairs (gclm_pass.hip: row_math_mirror): the tiles walk rows [0, H / 2), every lane takes row H - y along with row y
+    g.mirror = (mirror && g.vec == 4 && H % 2 == 0 && H >= 4) ? 1 : 0;
+    g.hrows = g.mirror ? H / 2 : H;
+    const int rows = g.hrows;
     g.wu = W / g.vec;
     auto waste = [](int used, int lanes) { return (int)(50.0 * (lanes - used) / lanes); };   // idle lanes, steps of 2 %
     if (g.wu <= kMaxTile) {
@@ -337,10 +370,11 @@ Geometry plan_geometry(int B, int H, int W, bool aligned16, int sweep_iters, int
     // The distortion models are VALU-bound: their per-workgroup prologue / epilogue is worth amortising over
     // 30 iterations where the image divides into whole blocks of that many rows (640x480: 8 blocks of 60 rows; same-allocation
     // A/B profiles/archive/r04_variant_huber_clamp.log: simple_radial -0.3 %, radial -1.2 %, simple_divisional -0.7 %, pinhole +0.4 %).
-    int builtin = 20;
-    if (camera_model != GCLM_PINHOLE && H % (g.rpi * 30) == 0) builtin = 30;
+    // Row pairs: an iteration is two rows of the image -- half the iterations for the same work per workgroup.
+    int builtin = g.mirror ? 10 : 20;
+    if (camera_model != GCLM_PINHOLE && rows % (g.rpi * (g.mirror ? 15 : 30)) == 0) builtin = g.mirror ? 15 : 30;
     int iters = (sweep_iters >= 1 && sweep_iters <= 4096) ? sweep_iters : builtin;   // gclm_set_sweep_iters (tuning / tests)
-    auto jobs = [&](int it) { return g.nstrips * g.wpt * ((H + g.rpi * it - 1) / (g.rpi * it)); };
+    auto jobs = [&](int it) { return g.nstrips * g.wpt * ((rows + g.rpi * it - 1) / (g.rpi * it)); };
     auto chunks = [&](int it) { return (jobs(it) + kBlock / 64 - 1) / (kBlock / 64); };
     while (iters > 2 && (long long)B * chunks(iters) < 2048) iters = iters > 5 ? iters / 2 : iters - 1;
     g.rows_per_block = g.rpi * iters;
@@ -459,7 +493,7 @@ int gclm_set_sweep_iters(gclm_handle* h, int iters) {
 int gclm_plan_cut(const gclm_handle* h, int B, int H, int W, int aligned16, int* rows_per_chunk, int* chunks_per_image) {
     if (!h) return -1;
     if (B < 1 || H < 1 || W < 1) return -3;
-    const Geometry geo = plan_geometry(B, H, W, aligned16 != 0, h->sweep_iters, h->cfg.camera_model);
+    const Geometry geo = plan_sweeps(h, B, H, W, aligned16 != 0, true);       // (as for the five planes of a complete field set)
     if (rows_per_chunk) *rows_per_chunk = geo.rows_per_block;
     if (chunks_per_image) *chunks_per_image = geo.nchunks;
     return 0;
@@ -470,6 +504,14 @@ int gclm_set_slat_plane(gclm_handle* h, int mode) {
     if (mode < -1 || mode > 1) return fail(h, -3, "gclm_set_slat_plane: mode %d not in {-1, 0, 1}", mode);
     h->slat_plane = mode;
     h->slat_refused = 0;
+    h->sh.active = false;
+    return 0;
+}
+
+int gclm_set_row_pairs(gclm_handle* h, int mode) {
+    if (!h) return -1;
+    if (mode < -1 || mode > 1) return fail(h, -3, "gclm_set_row_pairs: mode %d not in {-1, 0, 1}", mode);
+    h->row_pairs = mode;
     h->sh.active = false;
     return 0;
 }
@@ -584,7 +626,7 @@ static int run_solve(gclm_handle* h, const float* d_up, const float* d_lat, cons
     DeviceGuard guard(h->device);
     GCLM_HIP(h, guard.status);
     const bool al = is_aligned16(d_up) && is_aligned16(d_lat) && is_aligned16(d_up_conf) && is_aligned16(d_lat_conf);
-    const Geometry geo = plan_geometry(B, H, W, al, h->sweep_iters, h->cfg.camera_model);
+    const Geometry geo = plan_sweeps(h, B, H, W, al, d_up && d_up_conf && d_lat_conf);
     SolveCtx& c = h->ctx;
     c.cfg = h->cfg;
     c.B = B; c.H = H; c.W = W; c.nchunks = geo.nchunks;
@@ -593,7 +635,7 @@ static int run_solve(gclm_handle* h, const float* d_up, const float* d_lat, cons
     c.iso_final = (ia.cam == nullptr && ia.scales == nullptr && GCLM_ISO_FINAL) ? 1 : 0;
     if (int rc = setup_groups(h, B)) return rc;
     const bool es = h->cfg.early_stop != 0;
-    const bool fused_path = use_fused(h, B, geo);
+    const bool fused_path = !geo.mirror && use_fused(h, B, geo);      // (plan_sweeps only pairs rows where the step is not one launch)
     const bool keep_slat = slat_wanted(h, d_up, d_up_conf, d_lat_conf, geo, fused_path);
     if (int rc = ensure_workspace(h, B, geo.nchunks, c.n_groups)) return rc;
     ensure_slat(h, keep_slat ? (size_t)B * H * W : 0);
@@ -753,7 +795,7 @@ int gclm_shared_begin(gclm_handle* h, const float* d_up, const float* d_lat, con
     GCLM_HIP(h, guard.status);
     const bool al = is_aligned16(d_up) && is_aligned16(d_lat) && is_aligned16(d_up_conf) && is_aligned16(d_lat_conf);
     const int Bp = B_local > 0 ? B_local : 1;
-    h->sh.geo = plan_geometry(Bp, H, W, al, h->sweep_iters, h->cfg.camera_model);
+    h->sh.geo = plan_sweeps(h, Bp, H, W, al, d_up && d_up_conf && d_lat_conf);
     SolveCtx& c = h->ctx;
     c.cfg = h->cfg;
     c.B = B_local; c.H = H; c.W = W; c.nchunks = h->sh.geo.nchunks;

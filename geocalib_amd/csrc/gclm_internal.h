@@ -87,6 +87,8 @@ struct SweepArgs {
     float* slat;            // library-owned scratch plane (B,H,W) of sin(latitude_field), or nullptr (gclm_pass.hip: row_math)
     int slat_mode;          // 0: `lat` holds radians, nothing is stored; 1: ... and this sweep fills `slat`;
                             // 2: `lat` IS the filled scratch plane (sin(latitude) is loaded, not computed)
+    int hrows;              // rows the tiles walk: H, or H / 2 when a lane takes row H - y along with row y (mirror)
+    int mirror;             // 1: the row-pair walk (gclm_pass.hip: row_math_mirror); the geometry was planned for H / 2 rows
 };
 
 struct SolveCtx;
@@ -95,8 +97,11 @@ struct FusedArgs;
 struct Geometry {          // how a sweep is cut into blocks (column-stationary tiles, see gclm_pass.hip)
     int vec, nchunks;
     int wu, cu, nstrips, rpi, rows_per_block, wpt, jobs;
+    int mirror, hrows;     // the row-pair walk: tiles cover rows [0, H / 2), every lane takes the mirror row along
 };
-Geometry plan_geometry(int B, int H, int W, bool aligned16, int sweep_iters = 0, int camera_model = 0);
+Geometry plan_geometry(int B, int H, int W, bool aligned16, int sweep_iters = 0, int camera_model = 0, bool mirror = false);
+bool sweep_has_mirror(int camera_model);       // gclm_pass.hip: the model's five-plane float4 sweep has the row-pair instantiations
+bool sweep_mirror_builtin(int camera_model);   // ... and they are the library's own choice for it
 
 // gclm_pass.hip
 hipError_t launch_gradient_hessian(const float* d_J, const float* d_r, const float* d_w, int B, int N, int R, int P,

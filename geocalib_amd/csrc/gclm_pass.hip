@@ -45,6 +45,8 @@
 // type so the pairs live in adjacent registers straight out of the dwordx4 loads (LLVM's SLP
 // vectoriser finds some of these pairs on its own but pays for them with register shuffles and 2x
 // the VGPRs; it is switched off for this file, see the Makefile).
+#include <type_traits>
+
 #include "gclm_internal.h"
 #include "gclm_device.h"
 
@@ -60,6 +62,14 @@
 #endif
 #ifndef GCLM_RADIAL_WAVES
 #define GCLM_RADIAL_WAVES 3
+#endif
+#ifndef GCLM_MIRROR_MODELS
+#define GCLM_MIRROR_MODELS (1 << GCLM_SIMPLE_DIVISIONAL)   // models whose BUILT-IN choice is the row-pair walk (same-allocation A/B,
+                                                          // profiles/r06_variant_row_pairs.log: simple_divisional -14.2 % per sweep;
+                                                          // radial -1.9 %: has the instantiations, gclm_set_row_pairs(h, 1) picks them)
+#endif
+#ifndef GCLM_MIRROR_WAVES
+#define GCLM_MIRROR_WAVES 2    // the row-pair walkers (sweep_body: MIRROR) hold two rows' loads: 256 VGPRs
 #endif
 #ifndef GCLM_SLAT_PINHOLE
 #define GCLM_SLAT_PINHOLE 1    // pinhole has the scratch-plane instantiations too: never the built-in choice (memory-bound), only
@@ -462,29 +472,47 @@ __device__ __forceinline__ void pixel_accumulate_fast(const PBlock& P, const Hub
 //      (gclm_jacobian_fields);   2: the residuals r_up (2), r_lat (1) (gclm_residual_fields).
 // GMODE (simple_divisional): 0 = guarded radial terms; 1 = guard-free terms, recomputed with the guards when the
 // wave-uniform `patch` says a lane of this wave may need them (an if-without-else: the common path carries no copies)
-template <int MODEL, bool HAS_UP, bool LOGF, typename F, int EMIT = 0, int GMODE = 0>
-__device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& hk, F u, F px, float v, F dux, F duy,
-                                                 F slat, F cu, F cl, F (&acc)[Layout<MODEL>::NACC],
-                                                 [[maybe_unused]] float* j_up = nullptr,
-                                                 [[maybe_unused]] float* j_lat = nullptr,
-                                                 [[maybe_unused]] bool patch = false) {
-    constexpr bool DIST = MODEL != GCLM_PINHOLE;
-    constexpr int ND = Layout<MODEL>::ND, PN = Layout<MODEL>::PN;
-    const F r2 = vfma(u, u, vsplat(u, v * v));
-    [[maybe_unused]] F wx = vsplat(u, 0.f), uvw = vsplat(u, 0.f);
-    [[maybe_unused]] float wy = 0.f;
+//
+// The body is cut in two: `pixel_shared` holds everything that depends on (u, v^2) only -- r2, the radial terms, |ray|^2 and
+// its rsq -- and `pixel_stage` the rest.  The one-row walkers call them back to back (pixel_accumulate); the row-pair walker
+// (row_math_mirror) evaluates the first ONCE for rows y and H - y of a column.
+template <int MODEL, typename F>
+struct PixelShared {
+    F r2, uvw;              // uvw = uv . d(uv)/d(focal parameter) (general-focal columns only)
+    Radial<F> R;            // (what pixel_stage derives from these alone -- tau r2, |ray|^2, its rsq ... -- is merged by the
+};                          //  compiler's value numbering when two rows share one PixelShared: same operands, same values)
+template <int MODEL, bool LOGF, typename F, int GMODE = 0>
+__device__ __forceinline__ void pixel_shared(const PBlock& P, F u, float v, [[maybe_unused]] bool patch, PixelShared<MODEL, F>& S) {
+    S.r2 = vfma(u, u, vsplat(u, v * v));
+    S.uvw = vsplat(u, 0.f);
     if constexpr (!LOGF) {                               // LOGF: w = -(u,v), see pixel_accumulate_fast
-        wx = u * (-P.wfx);                               // d(uv)/d(focal parameter) = (wx, wy)
-        wy = -v * P.wfy;
-        uvw = vfma(u, wx, vsplat(u, v * wy));
+        const F wx = u * (-P.wfx);                       // d(uv)/d(focal parameter) = (wx, wy)
+        const float wy = -v * P.wfy;
+        S.uvw = vfma(u, wx, vsplat(u, v * wy));
     }
-    Radial<F> R;
-    radial_terms<MODEL, F, GMODE == 0>(P, r2, R);
+    radial_terms<MODEL, F, GMODE == 0>(P, S.r2, S.R);
     if constexpr (GMODE == 1) {
         if (patch) {
             asm volatile("; simple_divisional: guarded radial terms" ::: "memory");   // a real branch: never if-converted
-            radial_terms<MODEL, F, true>(P, r2, R);
+            radial_terms<MODEL, F, true>(P, S.r2, S.R);
         }
+    }
+}
+
+template <int MODEL, bool HAS_UP, bool LOGF, typename F, int EMIT = 0>
+__device__ __forceinline__ void pixel_stage(const PBlock& P, const HuberK& hk, const PixelShared<MODEL, F>& S, F u, F px, float v,
+                                            F dux, F duy, F slat, F cu, F cl, F (&acc)[Layout<MODEL>::NACC],
+                                            [[maybe_unused]] float* j_up = nullptr, [[maybe_unused]] float* j_lat = nullptr) {
+    constexpr bool DIST = MODEL != GCLM_PINHOLE;
+    constexpr int ND = Layout<MODEL>::ND, PN = Layout<MODEL>::PN;
+    const F r2 = S.r2;
+    const Radial<F>& R = S.R;
+    [[maybe_unused]] F wx = vsplat(u, 0.f);
+    [[maybe_unused]] const F uvw = S.uvw;
+    [[maybe_unused]] float wy = 0.f;
+    if constexpr (!LOGF) {
+        wx = u * (-P.wfx);
+        wy = -v * P.wfy;
     }
 
     if constexpr (HAS_UP) {
@@ -624,6 +652,17 @@ __device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& 
     }
 }
 
+template <int MODEL, bool HAS_UP, bool LOGF, typename F, int EMIT = 0, int GMODE = 0>
+__device__ __forceinline__ void pixel_accumulate(const PBlock& P, const HuberK& hk, F u, F px, float v, F dux, F duy,
+                                                 F slat, F cu, F cl, F (&acc)[Layout<MODEL>::NACC],
+                                                 [[maybe_unused]] float* j_up = nullptr,
+                                                 [[maybe_unused]] float* j_lat = nullptr,
+                                                 [[maybe_unused]] bool patch = false) {
+    PixelShared<MODEL, F> S;
+    pixel_shared<MODEL, LOGF, F, GMODE>(P, u, v, patch, S);
+    pixel_stage<MODEL, HAS_UP, LOGF, F, EMIT>(P, hk, S, u, px, v, dux, duy, slat, cu, cl, acc, j_up, j_lat);
+}
+
 // wave64 sum: four in-row DPP steps (quad_perm x2, row_half_mirror, row_mirror) leave the row sum in every lane of each
 // 16-lane row, row_bcast:15 / :31 carry the rows along -- six v_add_f32 with DPP operands, no LDS (a __shfl_xor butterfly:
 // six ds_bpermute round trips per value); the total is valid in lane 63 (kWaveSumLane).
@@ -715,7 +754,7 @@ __device__ __forceinline__ LaneJob<VEC> lane_job(const SweepArgs& a, const int c
     LaneJob<VEC> j;
     j.xu = strip * a.cu + tc;                            // unit column of the lane
     j.live = job < a.jobs && tr < a.rpi && j.xu < a.wu;
-    j.y_end = min((rowblock + 1) * a.rows_per_block, a.H);
+    j.y_end = min((rowblock + 1) * a.rows_per_block, a.hrows);     // hrows = H, or H / 2 for the row-pair walk (MIRROR)
     j.y = rowblock * a.rows_per_block + tr;
     j.off = ((uint32_t)j.y * (uint32_t)a.W + (uint32_t)(j.xu * VEC)) * 4u;
     j.off_step = (uint32_t)a.rpi * (uint32_t)a.W * 4u;
@@ -744,6 +783,31 @@ __device__ __forceinline__ RowData<VEC> load_row(const float* upx, const float* 
     return r;
 }
 
+// sin(latitude_field) of the lane's pixels of one row, per SLAT (see row_math)
+template <int VEC, int SLAT>
+__device__ __forceinline__ void row_slat(const RowData<VEC>& r, typename Lane<VEC>::F (&slat)[Lane<VEC>::kPairs],
+                                         [[maybe_unused]] float* slat_out, [[maybe_unused]] const uint32_t off) {
+    using L = Lane<VEC>;
+    using F = typename L::F;
+    // latitudes beyond +-pi/2 (never from the CNN head; a caller's own field may hold them): fold them into the
+    // polynomial's range.  Wave-uniform branch on a ballot: in-range data pays one max3 / max / cmp per 4 pixels.
+    if constexpr (SLAT == 2) {
+#pragma unroll
+        for (int k = 0; k < L::kPairs; ++k) slat[k] = L::get(r.vlat, k);
+    } else {
+        F lt[L::kPairs], t[L::kPairs];
+#pragma unroll
+        for (int k = 0; k < L::kPairs; ++k) { lt[k] = L::get(r.vlat, k); t[k] = lt[k] * lt[k]; }
+        if (__builtin_amdgcn_ballot_w64(L::max_of(t) > kHalfPiSq) != 0) {
+#pragma unroll
+            for (int k = 0; k < L::kPairs; ++k) { lt[k] = L::fold(lt[k]); t[k] = lt[k] * lt[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < L::kPairs; ++k) slat[k] = sin_halfpi(lt[k], t[k]);
+        if constexpr (SLAT == 1) L::st(slat_out, off, slat);
+    }
+}
+
 // The math of one loop iteration: image row y of the lane's column(s), from the loaded values into the accumulators.
 //
 // SLAT -- sin(latitude_field) (lm_optimizer.py:262,270) does not depend on the parameters, yet every sweep of a solve would
@@ -762,24 +826,8 @@ __device__ __forceinline__ void row_math(const PBlock& P, const HuberK& hk, cons
                                          [[maybe_unused]] float* slat_out = nullptr, [[maybe_unused]] const uint32_t off = 0) {
     using L = Lane<VEC>;
     using F = typename L::F;
-    // latitudes beyond +-pi/2 (never from the CNN head; a caller's own field may hold them): fold them into the
-    // polynomial's range.  Wave-uniform branch on a ballot: in-range data pays one max3 / max / cmp per 4 pixels.
     F slat[L::kPairs];
-    if constexpr (SLAT == 2) {
-#pragma unroll
-        for (int k = 0; k < L::kPairs; ++k) slat[k] = L::get(r.vlat, k);
-    } else {
-        F lt[L::kPairs], t[L::kPairs];
-#pragma unroll
-        for (int k = 0; k < L::kPairs; ++k) { lt[k] = L::get(r.vlat, k); t[k] = lt[k] * lt[k]; }
-        if (__builtin_amdgcn_ballot_w64(L::max_of(t) > kHalfPiSq) != 0) {
-#pragma unroll
-            for (int k = 0; k < L::kPairs; ++k) { lt[k] = L::fold(lt[k]); t[k] = lt[k] * lt[k]; }
-        }
-#pragma unroll
-        for (int k = 0; k < L::kPairs; ++k) slat[k] = sin_halfpi(lt[k], t[k]);
-        if constexpr (SLAT == 1) L::st(slat_out, off, slat);
-    }
+    row_slat<VEC, SLAT>(r, slat, slat_out, off);
     const float v = ((float)y - P.cy) * P.ify;
 #if GCLM_NOMATH     // measurement only: the memory-system ceiling of this exact access pattern
 #pragma unroll
@@ -813,6 +861,43 @@ __device__ __forceinline__ void row_math(const PBlock& P, const HuberK& hk, cons
 #endif
 }
 
+// MIRROR (radial / simple_divisional, float4 path, five planes, even H) -- ROW PAIRS.  Everything a radial model adds to the
+// pixel body is a function of r2 = u^2 + v^2 alone: the radial terms (simple_divisional: ~165 of its 415 VALU instructions per
+// 4 pixels), |ray|^2 and its rsq.  The principal point of every camera the library initialises is the image centre
+// (camera.py:136-152), so rows y and H - y of a column have v' = -v EXACTLY (integer pixel coordinates, cy = H / 2) and the
+// same r2 bit for bit.  A lane therefore walks the upper half of its column and takes row H - y along with row y: the second
+// row's body is the same inlined pixel code called with -v, and the compiler's value numbering merges every expression that
+// depends on (u, v^2) only -- same operations on the same values, hence the same per-pixel bits as the one-row walker; only
+// the order in which a lane adds its pixels changes.  Row 0 has no mirror image and row H / 2 is its own: they pair up with
+// each other WITHOUT sharing (wave-uniform `share`, false in the one iteration that holds row 0 and for an image whose
+// principal point is not the centre -- an explicit camera: the second row then gets its own v and its own radial terms).
+template <int MODEL, bool HAS_UP, bool LOGF, int VEC, int SLAT, bool SHARE>
+__device__ __forceinline__ void row_math_mirror(const PBlock& P, const HuberK& hk, const typename Lane<VEC>::F (&col_u)[Lane<VEC>::kPairs],
+                                                const typename Lane<VEC>::F (&col_px)[Lane<VEC>::kPairs], const int y, const int y2,
+                                                const RowData<VEC>& r, const RowData<VEC>& rm,
+                                                typename Lane<VEC>::F (&acc)[Layout<MODEL>::NACC], const bool col_zero,
+                                                const bool div_k_tiny, float* slat_out, const uint32_t off, const uint32_t off2) {
+    using L = Lane<VEC>;
+    using F = typename L::F;
+    F slat[L::kPairs], slat2[L::kPairs];
+    row_slat<VEC, SLAT>(r, slat, slat_out, off);
+    row_slat<VEC, SLAT>(rm, slat2, slat_out, off2);
+    const float v = ((float)y - P.cy) * P.ify;
+    const float v2 = SHARE ? -v : ((float)y2 - P.cy) * P.ify;
+    constexpr int GM = MODEL == GCLM_SIMPLE_DIVISIONAL ? 1 : 0;
+    const bool patch = div_k_tiny || __builtin_amdgcn_ballot_w64(col_zero && (v == 0.f || v2 == 0.f)) != 0;
+#pragma unroll
+    for (int k = 0; k < L::kPairs; ++k) {
+        PixelShared<MODEL, F> S;
+        pixel_shared<MODEL, LOGF, F, GM>(P, col_u[k], v, patch, S);
+        pixel_stage<MODEL, HAS_UP, LOGF, F>(P, hk, S, col_u[k], col_px[k], v, L::get(r.vux, k), L::get(r.vuy, k), slat[k],
+                                            L::get(r.vcu, k), L::get(r.vcl, k), acc);
+        if constexpr (!SHARE) pixel_shared<MODEL, LOGF, F, GM>(P, col_u[k], v2, patch, S);
+        pixel_stage<MODEL, HAS_UP, LOGF, F>(P, hk, S, col_u[k], col_px[k], v2, L::get(rm.vux, k), L::get(rm.vuy, k), slat2[k],
+                                            L::get(rm.vcu, k), L::get(rm.vcl, k), acc);
+    }
+}
+
 // COLUMN-STATIONARY mapping.  The unit of work is a WAVE JOB: 64 consecutive lanes of a tile of `rpi` rows x `cu`
 // units (float4 groups, or pixels in the scalar path) of ONE image, walking down `rows_per_block` rows, `rpi` rows
 // per iteration; lane f of the tile sits at (row f / cu, unit f % cu) and NEVER changes its column.  With a single
@@ -826,7 +911,7 @@ __device__ __forceinline__ void row_math(const PBlock& P, const HuberK& hk, cons
 //
 // PRE > 0 (one-launch-per-step kernel only): the values of the lane's first PRE iterations were requested by the caller
 // before its prologue (`pre`, with the lane's job `pj`), so their memory round trip runs under the prologue's.
-template <int MODEL, bool HAS_UP, bool HAS_UPC, bool HAS_LATC, bool LOGF, int VEC, int PRE = 0, int SLAT = 0>
+template <int MODEL, bool HAS_UP, bool HAS_UPC, bool HAS_LATC, bool LOGF, int VEC, int PRE = 0, int SLAT = 0, bool MIRROR = false>
 __device__ __forceinline__ void sweep_body(const SweepArgs& a, const PBlock& P, const int b, const int chunk,
                                            [[maybe_unused]] const LaneJob<VEC>* pj = nullptr,
                                            [[maybe_unused]] const RowData<VEC>* pre = nullptr) {
@@ -885,6 +970,33 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const PBlock& P, 
                 }
             }
         }
+        if constexpr (MIRROR) {
+            // row pairs (row_math_mirror): this lane's rows are [y, y_end) of the UPPER half, each with its mirror image.
+            // Three copies of the body, ONE of them hot: the shared-terms loop.  (A wave-uniform `share` tested inside a single
+            // loop costs 32-44 v_mov per iteration: the accumulators of the two bodies meet in phi copies.)
+            static_assert(PRE == 0 && VEC == 4 && HAS_UP && HAS_UPC && HAS_LATC, "row pairs: five-plane float4 sweep");
+            const bool centered = P.cy + P.cy == (float)a.H;                  // workgroup-uniform (scalar compare)
+            const uint32_t row_bytes = (uint32_t)a.W * 4u, col_bytes = (uint32_t)(xu * VEC) * 4u;
+            auto pair = [&](auto share) {
+                const int y2 = y == 0 ? (a.H >> 1) : a.H - y;
+                const uint32_t off2 = (uint32_t)y2 * row_bytes + col_bytes;
+                const RowData<VEC> r = load_row<HAS_UP, HAS_UPC, HAS_LATC, VEC>(upx, upy, lat, upc, latc, off);
+                const RowData<VEC> rm = load_row<HAS_UP, HAS_UPC, HAS_LATC, VEC>(upx, upy, lat, upc, latc, off2);
+                __builtin_amdgcn_sched_barrier(0);
+                row_math_mirror<MODEL, HAS_UP, LOGF, VEC, SLAT, decltype(share)::value>(P, hk, col_u, col_px, y, y2, r, rm, acc, col_zero,
+                                                                                    div_k_tiny, slat_out, off, off2);
+                y += a.rpi;
+                off += off_step;
+            };
+            if (centered) {
+                // row 0 has no mirror image (it pairs with row H / 2, nothing shared): the wave that holds it takes its
+                // first iteration through the unshared body
+                if (__builtin_amdgcn_ballot_w64(y == 0) != 0 && y < y_end) pair(std::false_type{});
+                while (y < y_end) pair(std::true_type{});
+            } else {
+                while (y < y_end) pair(std::false_type{});
+            }
+        } else
         for (; y < y_end; y += a.rpi, off += off_step) {
             const RowData<VEC> r = load_row<HAS_UP, HAS_UPC, HAS_LATC, VEC>(upx, upy, lat, upc, latc, off);
             // keep every load of the iteration ahead of the math: left alone, the scheduler sinks loads next to
@@ -917,13 +1029,13 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const PBlock& P, 
 // launch bounds: radial / simple_divisional are held to 168 VGPRs (3 waves per SIMD); simple_radial reaches 112 (4 waves) on its
 // own; the log-focal pinhole sweep is held to 80 (6 waves); its general-focal instantiation would spill at 80 and keeps its own
 // 96, and so do its scratch-plane instantiations SLAT != 0 (never the library's built-in choice for pinhole)
-template <int MODEL, bool HAS_UP, bool HAS_UPC, bool HAS_LATC, bool LOGF, int VEC, int SLAT = 0>
-__global__ __launch_bounds__(kBlock, (VEC == 4 && MODEL == GCLM_RADIAL) ? GCLM_RADIAL_WAVES : (VEC == 4 && MODEL > GCLM_RADIAL) ? GCLM_DIV_WAVES : (VEC == 4 && MODEL == GCLM_SIMPLE_RADIAL) ? 4 : (VEC == 4 && MODEL == GCLM_PINHOLE && LOGF) ? (SLAT == 0 ? GCLM_PINHOLE_WAVES : 5) : GCLM_MIN_WAVES) void sweep_kernel(
+template <int MODEL, bool HAS_UP, bool HAS_UPC, bool HAS_LATC, bool LOGF, int VEC, int SLAT = 0, bool MIRROR = false>
+__global__ __launch_bounds__(kBlock, MIRROR ? GCLM_MIRROR_WAVES : (VEC == 4 && MODEL == GCLM_RADIAL) ? GCLM_RADIAL_WAVES : (VEC == 4 && MODEL > GCLM_RADIAL) ? GCLM_DIV_WAVES : (VEC == 4 && MODEL == GCLM_SIMPLE_RADIAL) ? 4 : (VEC == 4 && MODEL == GCLM_PINHOLE && LOGF) ? (SLAT == 0 ? GCLM_PINHOLE_WAVES : 5) : GCLM_MIN_WAVES) void sweep_kernel(
     const SweepArgs a) {
     if (stop_fired_before(a.ctrl, a.stop_step)) return;   // batch-global early stop, no host sync
     const int b = blockIdx.y, chunk = blockIdx.x;
     const PBlock P = a.pb[b];                            // workgroup-uniform -> scalar loads
-    sweep_body<MODEL, HAS_UP, HAS_UPC, HAS_LATC, LOGF, VEC, 0, SLAT>(a, P, b, chunk);
+    sweep_body<MODEL, HAS_UP, HAS_UPC, HAS_LATC, LOGF, VEC, 0, SLAT, MIRROR>(a, P, b, chunk);
 }
 
 // ONE launch per LM step for small batches (the interactive B = 1 case of the reference's demo, interactive_demo.py:403):
@@ -1229,6 +1341,25 @@ hipError_t dispatch(const SweepArgs& a, hipStream_t s) {
         if (logf) hipLaunchKernelGGL((sweep_kernel<MODEL, U, UC, LC, VEC == 4, VEC>), grid, block, 0, s, a); \
         else hipLaunchKernelGGL((sweep_kernel<MODEL, U, UC, LC, false, VEC>), grid, block, 0, s, a);    \
     } while (0)
+    // row pairs (sweep_body: MIRROR): the five-plane float4 sweeps of radial / simple_divisional over an even number of rows
+    if (a.mirror != 0) {
+        if constexpr (VEC == 4 && (MODEL == GCLM_RADIAL || MODEL == GCLM_SIMPLE_DIVISIONAL)) {
+            if (!(up && upc && latc) || (a.H & 1) || a.hrows * 2 != a.H || a.slat_mode < 0 || a.slat_mode > 2 ||
+                (a.slat_mode != 0 && a.slat == nullptr))
+                return hipErrorInvalidValue;
+#define GCLM_LAUNCH_MIRROR(LF)                                                                                              \
+    do {                                                                                                                    \
+        if (a.slat_mode == 0) hipLaunchKernelGGL((sweep_kernel<MODEL, true, true, true, LF, 4, 0, true>), grid, block, 0, s, a);      \
+        else if (a.slat_mode == 1) hipLaunchKernelGGL((sweep_kernel<MODEL, true, true, true, LF, 4, 1, true>), grid, block, 0, s, a); \
+        else hipLaunchKernelGGL((sweep_kernel<MODEL, true, true, true, LF, 4, 2, true>), grid, block, 0, s, a);             \
+    } while (0)
+            if (logf) GCLM_LAUNCH_MIRROR(true); else GCLM_LAUNCH_MIRROR(false);
+#undef GCLM_LAUNCH_MIRROR
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     // the sin(latitude) scratch plane (row_math: SLAT) exists for the five-plane float4 sweeps of the distortion models
     if constexpr (VEC == 4 && (MODEL != GCLM_PINHOLE || GCLM_SLAT_PINHOLE)) {
         if (a.slat_mode != 0) {
@@ -1292,6 +1423,9 @@ hipError_t launch_sweep(int camera_model, const SweepArgs& a, hipStream_t s) {
         default: return hipErrorInvalidValue;
     }
 }
+
+bool sweep_has_mirror(int camera_model) { return camera_model == GCLM_RADIAL || camera_model == GCLM_SIMPLE_DIVISIONAL; }
+bool sweep_mirror_builtin(int camera_model) { return sweep_has_mirror(camera_model) && ((GCLM_MIRROR_MODELS >> camera_model) & 1) != 0; }
 
 bool sweep_has_slat_plane(int camera_model) {
     return camera_model > GCLM_PINHOLE ? camera_model <= GCLM_SIMPLE_DIVISIONAL : (camera_model == GCLM_PINHOLE && GCLM_SLAT_PINHOLE != 0);

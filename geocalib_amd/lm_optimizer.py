@@ -60,12 +60,18 @@ class _Handle:
         self.key = cfg.key()
         self.device = cfg.device
         self.paced = 0
+        self.row_pairs = -1
         self.signature = None           # LMOptimizer._config_signature the handle was last configured for
 
     def set_paced(self, depth: int):
         if depth != self.paced:
             _lib.check(_lib.load().gclm_set_paced_launches(self.ptr, int(depth)), self.ptr, "gclm_set_paced_launches")
             self.paced = depth
+
+    def set_row_pairs(self, mode: int):
+        if mode != self.row_pairs:
+            _lib.check(_lib.load().gclm_set_row_pairs(self.ptr, int(mode)), self.ptr, "gclm_set_row_pairs")
+            self.row_pairs = mode
 
     def destroy(self):
         if self.ptr:
@@ -287,6 +293,12 @@ class LMOptimizer(nn.Module):
     # the launches after the stop).  For callers that read the result right away; GeoCalib sets 3.  Results are unaffected.
     paced_launches = 0
 
+    # Host-side knob without a reference counterpart (include/gclm.h: gclm_set_row_pairs).  The sweep of a radial model may
+    # take row H - y along with row y and evaluate what depends on r^2 once for both (same per-pixel values, another order of
+    # additions: results equal the one-row walk's to float32 summation order).  None: the library decides (batches of
+    # simple_divisional images); False: never -- the one-row walk, bit for bit; True: wherever the sweep can (radial too).
+    row_pairs = None
+
     def _handle(self, device: torch.device, stream: int = None) -> _Handle:
         """The gclm_handle of (device, stream): solves issued from different torch streams (e.g. the CNN of batch k+1
         overlapping the LM of batch k) get different workspaces; the same stream reuses its own, in order."""
@@ -299,6 +311,7 @@ class LMOptimizer(nn.Module):
         if h is not None and h.signature == sig:         # the common case of a serving loop: nothing to rebuild
             self._handles[key] = h
             h.set_paced(int(self.paced_launches))
+            h.set_row_pairs(-1 if self.row_pairs is None else int(bool(self.row_pairs)))
             return h
         cfg = self._config(idx)
         if h is None:
@@ -313,6 +326,7 @@ class LMOptimizer(nn.Module):
         self._handles[key] = h            # most recently used last
         h.signature = sig
         h.set_paced(int(self.paced_launches))
+        h.set_row_pairs(-1 if self.row_pairs is None else int(bool(self.row_pairs)))
         return h
 
     @staticmethod

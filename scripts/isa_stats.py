@@ -1,11 +1,12 @@
 """Instruction statistics of the sweep kernel's main loop (run in the build container: hipcc cross-compiles).
 
-usage: python scripts/isa_stats.py [--json OUT] [--dump SYMBOL_SUBSTRING] [--slat 0|1|2] [MODEL ...]
+usage: python scripts/isa_stats.py [--json OUT] [--dump SYMBOL_SUBSTRING] [--slat 0|1|2] [--mirror 0|1] [MODEL ...]
        MODEL in {0 pinhole, 1 simple_radial, 2 radial, 3 simple_divisional}; default: all four.
 Looks at the instantiation sweep_kernel<MODEL, HAS_UP=1, HAS_UPC=1, HAS_LATC=1, LOGF=1, VEC=4> (the loop sweep of the
 default conf with both confidences: what bench.py runs) by its mangled template arguments, independent of how many
 template parameters precede / follow them; --slat picks the SLAT instantiation (0: sin(latitude) computed per sweep, 1: computed
 and stored into the scratch plane = the first sweep of a solve, 2: loaded from it = every later sweep; gclm_pass.hip: row_math).
+--mirror 1 picks the row-pair walker (radial / simple_divisional: one loop iteration = two rows = 8 pixels per lane).
 EXTRA="-D..." adds compile flags (A/B switches of gclm_pass.hip)."""
 import collections
 import json
@@ -30,6 +31,9 @@ def main():
     slat = 0
     if "--slat" in args:
         i = args.index("--slat"); slat = int(args[i + 1]); del args[i:i + 2]
+    mirror = 0
+    if "--mirror" in args:
+        i = args.index("--mirror"); mirror = int(args[i + 1]); del args[i:i + 2]
     models = [int(a) for a in args] or [0, 1, 2, 3]
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast-honor-pragmas",
                     "-fno-slp-vectorize", *os.environ.get("PASS_BASE_EXTRA", "-mllvm -disable-vector-combine").split(), *os.environ.get("EXTRA", "").split(), "-S", "--cuda-device-only", "-o", asm, src],
@@ -38,7 +42,7 @@ def main():
     results = {}
     for m_id in models:
         # sweep_kernel<MODEL, true, true, true, true(LOGF), 4(VEC)>
-        pat = r"^(_ZN4gclm\S*sweep_kernelILi%dELb1ELb1ELb1ELb1ELi4ELi%dE\S*):\s*;.*?\n(.*?)\.amdhsa_kernel" % (m_id, slat)
+        pat = r"^(_ZN4gclm\S*sweep_kernelILi%dELb1ELb1ELb1ELb1ELi4ELi%dELb%dE\S*):\s*;.*?\n(.*?)\.amdhsa_kernel" % (m_id, slat, mirror)
         m = re.search(pat, text, re.S | re.M)
         if not m:
             print(f"model {m_id}: instantiation not found (template signature changed?)")
@@ -85,7 +89,7 @@ def main():
         results[NAMES[m_id]] = {"loop_instructions": len(ops), "loop_instructions_with_rare_blocks": len(ops_all),
                                 "rare_blocks_valu": sorted(rare_valu.values()), "other_loops_valu": other_loops, "cndmask": c.get("v_cndmask_b32_e32", 0) + c.get("v_cndmask_b32_e64", 0),
                                 "valu": valu, "valu_packed": pk, "valu_transcendental": trans,
-                                "valu_mov": mov, "global_loads": loads, "mfma": mfma, "pixels_per_iteration": 4,
+                                "valu_mov": mov, "global_loads": loads, "mfma": mfma, "pixels_per_iteration": 8 if mirror else 4,
                                 "vgprs": int(nv.group(1)) if nv else None, "scratch_bytes": int(sc.group(1)) if sc else None,
                                 "top": c.most_common(12)}
         print(f"{NAMES[m_id]}: loop {len(ops)} instr, VALU {valu} (packed {pk}, trans {trans}, mov {mov}), "

@@ -47,12 +47,12 @@ def test_code_object_targets_gfx950():
 
 def test_default_config_matches_reference_defaults():
     lib = _lib.load()
-    assert lib.gclm_version() == 600 == _lib.ABI_VERSION
+    assert lib.gclm_version() == 610 == _lib.ABI_VERSION
     header = open(HEADER).read()
-    assert re.search(r"#define GCLM_VERSION\s+(\d+)", header).group(1) == "600"
+    assert re.search(r"#define GCLM_VERSION\s+(\d+)", header).group(1) == "610"
     cfg = _lib.GclmConfig()
     assert lib.gclm_default_config(C.byref(cfg)) == 0
-    assert (cfg.struct_size, cfg.abi_version, cfg.device) == (C.sizeof(_lib.GclmConfig), 600, 0)
+    assert (cfg.struct_size, cfg.abi_version, cfg.device) == (C.sizeof(_lib.GclmConfig), 610, 0)
     assert lib.gclm_abi_config_size() == C.sizeof(_lib.GclmConfig)
     # LMOptimizer.default_conf, lm_optimizer.py:144-162
     assert (cfg.camera_model, cfg.shared_intrinsics, cfg.num_steps, cfg.fix_lambda, cfg.early_stop) == (0, 0, 30, 0, 1)
@@ -86,7 +86,7 @@ def test_create_rejects_a_stale_caller():
     lib.gclm_default_config(C.byref(cfg))
     cfg.abi_version = 100
     assert lib.gclm_create(C.byref(h), C.byref(cfg)) == -5 and not h
-    assert "ABI mismatch" in _lib.last_error(None) and "100" in _lib.last_error(None) and "600" in _lib.last_error(None)
+    assert "ABI mismatch" in _lib.last_error(None) and "100" in _lib.last_error(None) and "610" in _lib.last_error(None)
     lib.gclm_default_config(C.byref(cfg))
     cfg.struct_size = 18 * 4
     assert lib.gclm_create(C.byref(h), C.byref(cfg)) == -5 and "struct_size 72" in _lib.last_error(None)

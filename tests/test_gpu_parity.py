@@ -45,9 +45,10 @@ def to_np(out):
     return res
 
 
-def run(conf, data, dev, training=False):
+def run(conf, data, dev, training=False, row_pairs=None):
     from geocalib_amd import LMOptimizer
     opt = LMOptimizer(dict(conf))
+    opt.row_pairs = row_pairs            # None: the library's choice; True: the row-pair walk wherever the sweep has it
     opt = opt.train() if training else opt.eval()
     out = opt(to_dev(data, dev))
     torch.cuda.synchronize()
@@ -56,10 +57,15 @@ def run(conf, data, dev, training=False):
 
 # ------------------------------------------------------------------ against the reference's goldens
 
+@pytest.mark.parametrize("row_pairs", [None, True])
 @pytest.mark.parametrize("setname,variant", golden_cases(ALL_MODELS))
-def test_hip_matches_reference_small(dev, setname, variant):
+def test_hip_matches_reference_small(dev, setname, variant, row_pairs):
+    """`row_pairs`: the same goldens, same gates, with the sweep walking row pairs (gclm_set_row_pairs(h, 1): radial /
+    simple_divisional sets with both confidences; the library's own choice for inputs this small is the one-row walk)."""
+    if row_pairs and not any(m in setname for m in ("radial", "divisional")) or (row_pairs and "simple_radial" in setname):
+        pytest.skip("the row-pair walk exists for radial / simple_divisional")
     ref = golden_outputs(setname, variant)
-    out = run(conf_for(setname, variant), data_for(setname, variant), dev)
+    out = run(conf_for(setname, variant), data_for(setname, variant), dev, row_pairs=row_pairs)
     tol = dict(TOL)
     if "divisional" in setname:
         # north_star's 1e-4 plus 3 x what the REFERENCE itself moves on this case under 1-ulp input perturbations
@@ -91,8 +97,9 @@ def test_hip_matches_reference_full_size(dev, model):
     assert np.array_equal(out["stop_at"], ref["stop_at"])
 
 
+@pytest.mark.parametrize("row_pairs", [None, True])
 @pytest.mark.parametrize("model,idx", [("radial", (0, 1)), ("simple_divisional", (2, 5))])
-def test_hip_matches_reference_full_size_other_models(dev, model, idx):
+def test_hip_matches_reference_full_size_other_models(dev, model, idx, row_pairs):
     """The two non-BASELINE camera models at the BASELINE image size (640x480, 20 iterations) against the REFERENCE's own
     result (tests/golden/make_golden_full_rd.py): north_star's 1e-4, plus 10 x the reference's own 1-ulp input
     sensitivity on these images (2e-4 at most: both are in the regime where the reference reproduces itself)."""
@@ -102,7 +109,7 @@ def test_hip_matches_reference_full_size_other_models(dev, model, idx):
     data, cams, gravs = synth.make_fields(1234, idx, model, 480, 640)
     chk = np.array([np.float64(np.asarray(v, np.float64).sum()) for _, v in sorted(data.items())])
     assert np.allclose(chk, g[f"{model}/input_checksum"], rtol=1e-9, atol=1e-3)
-    out = run({"camera_model": model, "num_steps": 20, "early_stop": False}, data, dev)
+    out = run({"camera_model": model, "num_steps": 20, "early_stop": False}, data, dev, row_pairs=row_pairs)
     ref = {k.split("/", 1)[1]: g[k] for k in g.files if k.startswith(model + "/")}
     d = result_spread(out, ref)
     assert (d < 1e-4 + 10.0 * ref["spread"]).all(), (model, d, ref["spread"])
@@ -1400,15 +1407,27 @@ def test_bench_single_gpu_line_carries_secondary_overlap_and_best_of_n(dev):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["streams"] == 1
     sec = out["secondary"]
-    assert set(sec) == {"simple_radial_B832", "shared16_pinhole"}
-    for rec in sec.values():
+    assert set(sec) == {"simple_radial_B832", "shared16_pinhole", "simple_divisional_B832"}
+    for name, rec in sec.items():
         assert rec["value"] > 0 and rec["steps"] == 5 and rec["roofline"]["launches_timed"] == 5 * 21
         assert 0 < rec["roofline"]["frac"] < 1 and rec["check"]["median_focal_rel_err_vs_gt"] < 5e-3
         # parity INSIDE the record: the first 64 images of the timed batch against the CPU oracle
         vo = rec["check"]["vs_oracle"]
-        assert vo["images"] == 64 and vo["within_gate"] is True and vo["gate"] == 1e-4, vo
-        assert max(vo["max_focal_rel"], vo["max_gravity_abs"], vo["max_final_cost_rel"]) <= 1e-4
+        assert vo["images"] == 64 and vo["gate"] == 1e-4, vo
+        if "divisional" in name:
+            # the model's k column cancels in float32 (camera.py:913; the reference itself moves by 3e-4 under 1-ulp inputs,
+            # tests/golden/make_golden_div_small.py): the record states how many of the 64 images sit within 1e-4 and the medians
+            assert vo["images_within_gate"] >= 48 and max(vo["median_focal_rel"], vo["median_gravity_abs"], vo["median_final_cost_rel"]) <= 1e-4, vo
+        else:
+            assert vo["within_gate"] is True and vo["images_within_gate"] == 64, vo
+            assert max(vo["max_focal_rel"], vo["max_gravity_abs"], vo["max_final_cost_rel"]) <= 1e-4
         assert 0 < rec["roofline"]["frac"] <= rec["roofline"]["read_ceiling_frac"] * 1.02 <= 1.05
+    # ... the control for the row-pair walk of simple_divisional's sweep: the same solves with the one-row walk, then the default again
+    sd = sec["simple_divisional_B832"]
+    rp = sd["row_pairs_off"]
+    assert rp["value"] > 0 and 0 < rp["frac"] < sd["roofline"]["frac"] and rp["on_again"]["frac"] > rp["frac"], (rp, sd["roofline"])
+    assert rp["median_focal_rel_vs_default"] < 1e-5 and rp["median_gravity_abs_vs_default"] < 1e-5, rp
+    assert "row_pairs_off" not in sec["simple_radial_B832"]
     # ... and the control for the scratch plane on the driver's own box: the same solves with the plane off, then on again
     sr = sec["simple_radial_B832"]
     assert sr["slat_plane_bytes"] == 832 * 480 * 640 * 4 and sr["workspace_bytes"] - sr["slat_plane_bytes"] < 16 * 2 ** 20
@@ -1993,6 +2012,111 @@ def test_slat_plane_changes_nothing_but_the_workspace(dev, model):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("model", ["radial", "simple_divisional"])
+def test_row_pairs_equal_the_one_row_walk_to_summation_order(dev, model):
+    """gclm_set_row_pairs: a lane of the sweep takes row H - y along with row y and evaluates what depends on r^2 once for both
+    (gclm_pass.hip: row_math_mirror).  Same per-pixel values, another order of a lane's additions:
+      * after ONE LM step (nothing amplifies yet) the two walks agree to float32 summation order on every shape -- whole
+        tiles, ragged tiles, strips, tiny images; both parametrisations; `scales` (anisotropic focal, principal point off
+        the centre of the field: the pairs are walked WITHOUT sharing, decided per image on the device); an explicit
+        off-centre camera through optimize(); with and without the scratch plane;
+      * where the sweep has no row-pair walker (odd height, a missing confidence, the scalar path) the knob changes nothing,
+        bit for bit; mode 0 and the built-in choice on a small launch are the one-row walk, bit for bit;
+      * the walk is deterministic (same call, same bits) and shard-invariant (images are independent);
+      * a full solve of a BATCH (the built-in choice for simple_divisional: > 768 workgroups) recovers the ground truth and
+        stays within the fuzz gate of the one-row solve on the well-conditioned images.
+    The gates against the REFERENCE run on the row-pair walk in test_hip_matches_reference_small / _full_size_other_models."""
+    from conftest import MEASURED, result_spread
+    from geocalib_amd import LMOptimizer, _lib
+    from geocalib_amd.camera import camera_models
+    from geocalib_amd.gravity import Gravity
+    lib = _lib.load()
+    probe = LMOptimizer({"camera_model": model})._handle(dev)
+    assert lib.gclm_set_row_pairs(None, 1) == -1
+    assert lib.gclm_set_row_pairs(probe.ptr, 2) == -3 and "gclm_set_row_pairs" in _lib.last_error(probe.ptr)
+    assert lib.gclm_set_row_pairs(probe.ptr, -1) == 0
+
+    def solve(conf, data, pairs, slat=-1, fused=-1):
+        opt = LMOptimizer({"camera_model": model, **conf}).eval()
+        opt.row_pairs = pairs
+        opt.overlap_streams = 1
+        h = opt._handle(dev)
+        _lib.check(lib.gclm_set_slat_plane(h.ptr, slat), h.ptr, "gclm_set_slat_plane")
+        _lib.check(lib.gclm_set_fused_steps(h.ptr, fused), h.ptr, "gclm_set_fused_steps")
+        out = to_np(opt(data))
+        torch.cuda.synchronize()
+        return out
+
+    def same_bits(a, b):
+        return all(np.array_equal(a[k], b[k], equal_nan=True) for k in a)
+
+    one_step = {"num_steps": 1, "early_stop": False}
+    worst = np.zeros(4)
+    for (B, H, W) in ((6, 240, 320), (3, 230, 324), (2, 64, 2600), (5, 6, 8), (2, 480, 640)):
+        data, _, _ = synth_device(model, B, H, W, dev, seed=5)
+        for extra in ({}, {"use_log_focal": False, "use_spherical_manifold": False}):
+            for more in ({}, {"scales": torch.tensor([0.8, 1.25], device=dev)}):
+                d = {**data, **more}
+                off, on = solve({**one_step, **extra}, d, False), solve({**one_step, **extra}, d, True)
+                sp = result_spread(on, off)
+                worst = np.maximum(worst, sp if H * W >= 1000 else 0.0)
+                # (48 pixels: simple_divisional's cost moves by 1e-4 for a change of k in its last bit -- the walk over a
+                #  tiny image is checked for its indexing, which would show at O(1))
+                assert (sp < (1e-5 if H * W >= 1000 else 1e-3)).all(), (model, (B, H, W), extra, list(more), sp)
+                # (the 2600 x 64 strip: focal and distortion are not separable on it -- H_ff H_kk - H_fk^2 cancels to the last
+                #  bits, the oracle's own float32 covariance comes out with negative variances there: no uncertainty to compare)
+                for k in ("covariance", "focal_uncertainty", "gravity_uncertainty") if W < 2048 and H * W >= 1000 else ():
+                    assert np.abs(on[k] - off[k]).max() <= 1e-3 * np.abs(off[k]).max(), (model, (B, H, W), extra, k)
+                assert not same_bits(on, off) or H * W < 100, "the knob did not reach the sweep"
+                # deterministic; indifferent to the scratch plane; mode 0 = built-in choice on a launch this small
+                assert same_bits(on, solve({**one_step, **extra}, d, True))
+                assert same_bits(on, solve({**one_step, **extra}, d, True, slat=0))
+                assert same_bits(off, solve({**one_step, **extra}, d, None, fused=0))
+    MEASURED[f"row_pairs/{model}/one_step_worst"] = worst.tolist()
+    # no row-pair walker for these: the knob must change nothing
+    data, _, _ = synth_device(model, 3, 231, 320, dev, seed=6)                      # odd height
+    assert same_bits(solve(one_step, data, False), solve(one_step, data, True))
+    data, _, _ = synth_device(model, 3, 240, 320, dev, seed=6)
+    bare = {k: v for k, v in data.items() if k != "up_confidence"}                  # four planes
+    assert same_bits(solve(one_step, bare, False), solve(one_step, bare, True))
+    odd = {k: v[..., :318].contiguous() for k, v in data.items()}                   # 318 px: the scalar path
+    assert same_bits(solve(one_step, odd, False), solve(one_step, odd, True))
+    # an explicit camera whose principal point is not the centre (optimize(): gclm_solve)
+    data, gt_cam, gt_grav = synth_device(model, 4, 240, 320, dev, seed=9)
+    cam0 = gt_cam.clone()
+    cam0[:, 4] += 3.0
+    cam0[:, 5] -= 2.0
+    res = {}
+    for pairs in (False, True):
+        opt = LMOptimizer({"camera_model": model, "num_steps": 2, "early_stop": False}).eval()
+        opt.row_pairs = pairs
+        opt.setup_optimization_and_priors(data)
+        c, g, info = opt.optimize(data, camera_models[model](cam0.clone()), Gravity(gt_grav.clone()))
+        res[pairs] = {"camera": c._data.cpu().numpy(), "gravity": g._data.cpu().numpy(),
+                      "final_cost": info["final_cost"].cpu().numpy(), "initial_cost": info["initial_cost"].cpu().numpy()}
+    assert (result_spread(res[True], res[False]) < 1e-5).all(), result_spread(res[True], res[False])
+    assert np.array_equal(res[True]["camera"][:, 4:6], cam0[:, 4:6].cpu().numpy())
+    # a batch: the built-in choice pairs the rows of simple_divisional (not of radial), shards agree with the whole
+    B, H, W = 416, 480, 640          # (halves of 208 images: still cut into workgroups like the whole batch, plan_geometry)
+    data, gt_cam, gt_grav = synth_device(model, B, H, W, dev, seed=12)
+    conf = {"num_steps": 20, "early_stop": False}
+    auto, on, off = solve(conf, data, None), solve(conf, data, True), solve(conf, data, False)
+    assert same_bits(auto, on if model == "simple_divisional" else off), "built-in choice"
+    half = solve(conf, {k: v[B // 2:] for k, v in data.items()}, True)
+    assert all(np.array_equal(half[k], on[k][B // 2:], equal_nan=True) for k in ("camera", "gravity", "final_cost", "covariance"))
+    f_err = np.abs(on["camera"][:, 3] / gt_cam[:, 3].cpu().numpy() - 1)
+    assert np.median(f_err) < 1e-3, np.median(f_err)
+    sp = np.array([result_spread({k: on[k][i:i + 1] for k in on}, {k: off[k][i:i + 1] for k in off}) for i in range(B)])
+    gate = FUZZ_GATE[model] * (1.0 if model == "radial" else 10.0)
+    ok = (sp < gate).all(1)
+    # (radial: 3 of 416 images pass through a k clamp with a near-singular (focal, k1, k2) block and amplify rounding-level
+    # differences a thousandfold, like fuzz 115/45 -- profiles/r06_fuzz_115_45_diagnosis.log)
+    MEASURED[f"row_pairs/{model}/batch"] = {"median_spread": np.median(sp, 0).tolist(), "worst": sp.max(0).tolist(), "within_gate": float(ok.mean())}
+    # (simple_divisional's k column cancels in float32, camera.py:913: a few images of a hundred amplify ANY rounding-level
+    # difference -- the reference moves as far under 1-ulp input perturbations; the median is what a broken walk would move)
+    assert np.median(sp, 0).max() < 2e-5 and ok.mean() >= (0.98 if model == "radial" else 0.9), (np.median(sp, 0), sp.max(0), ok.mean())
+
+
 @pytest.mark.parametrize("model", ["simple_radial", "simple_divisional"])
 def test_slat_plane_is_optional_and_exactly_sized(dev, model):
     """VERDICT r05 #3 / ADVICE r05: the sin(latitude) scratch plane is an allocation of its own, of exactly B x H x W x 4 bytes

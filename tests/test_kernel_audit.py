@@ -44,21 +44,26 @@ def test_no_sweep_kernel_carries_an_lds_array_or_scratch_it_was_not_given(tmp_pa
     assert all(v["lds"] <= 2816 for v in fused.values()), {n: v for n, v in fused.items() if v["lds"] > 2816}
     # scratch: none, except general-focal (LOGF = 0: a non-default conf, or the ONE final sweep of a solve with fx != fy)
     # instantiations held to 168 VGPRs: two of simple_divisional (8 / 16 B) and radial's scratch-plane reader (8 B)
-    # -- pinned by their exact template arguments <MODEL, HAS_UP, HAS_UPC, HAS_LATC, LOGF = 0, VEC = 4, SLAT>, with the bytes each
+    # -- pinned by their exact template arguments <MODEL, HAS_UP, HAS_UPC, HAS_LATC, LOGF = 0, VEC = 4, SLAT, MIRROR = 0>, with the bytes each
     # may spill (a substring match plus a count would let any other instantiation start spilling unnoticed)
     spilling = {re.search(r"sweep_kernelI(\w+?)EEv|fused_step_kernelI(\w+?)EEv", n).group(0): v["scratch"]
                 for n, v in {**sweeps, **fused}.items() if v["scratch"]}
-    allowed = {"sweep_kernelILi3ELb1ELb0ELb1ELb0ELi4ELi0EEEv": 8,      # simple_divisional, no up confidence, general focal
-               "sweep_kernelILi3ELb1ELb1ELb1ELb0ELi4ELi0EEEv": 16,     # simple_divisional, five planes, general focal
-               "sweep_kernelILi2ELb1ELb1ELb1ELb0ELi4ELi2EEEv": 8}      # radial, scratch-plane reader, general focal
+    allowed = {"sweep_kernelILi3ELb1ELb0ELb1ELb0ELi4ELi0ELb0EEEv": 8,      # simple_divisional, no up confidence, general focal
+               "sweep_kernelILi3ELb1ELb1ELb1ELb0ELi4ELi0ELb0EEEv": 16,     # simple_divisional, five planes, general focal
+               "sweep_kernelILi2ELb1ELb1ELb1ELb0ELi4ELi2ELb0EEEv": 8}      # radial, scratch-plane reader, general focal
     assert all(spilling[n] <= allowed.get(n, 0) for n in spilling), (spilling, allowed)
     # the BASELINE instantiations keep their occupancy: pinhole 80 VGPRs (6 waves / SIMD), simple_radial <= 128 (4 waves)
-    main = {m: next(v for n, v in sweeps.items() if f"sweep_kernelILi{m}ELb1ELb1ELb1ELb1ELi4ELi0E" in n) for m in range(4)}
+    main = {m: next(v for n, v in sweeps.items() if f"sweep_kernelILi{m}ELb1ELb1ELb1ELb1ELi4ELi0ELb0E" in n) for m in range(4)}
     assert main[0]["vgpr"] <= 80 and main[1]["vgpr"] <= 128 and main[2]["vgpr"] <= 168 and main[3]["vgpr"] <= 168, main
     # ... and so do the scratch-plane instantiations (SLAT = 1: the first sweep of a solve stores sin(latitude), SLAT = 2: the
     # later sweeps load it) that the distortion models run by default -- same waves per SIMD as the plain sweep, no scratch
     for slat in (1, 2):
         for logf in (0, 1):
-            inst = {m: next(v for n, v in sweeps.items() if f"sweep_kernelILi{m}ELb1ELb1ELb1ELb{logf}ELi4ELi{slat}E" in n) for m in range(4)}
+            inst = {m: next(v for n, v in sweeps.items() if f"sweep_kernelILi{m}ELb1ELb1ELb1ELb{logf}ELi4ELi{slat}ELb0E" in n) for m in range(4)}
             assert inst[0]["vgpr"] <= 96 and inst[1]["vgpr"] <= 128 and inst[2]["vgpr"] <= 168 and inst[3]["vgpr"] <= 168, (slat, logf, inst)
             assert all(v["scratch"] == 0 for m, v in inst.items() if logf == 1), (slat, logf, inst)
+    # the row-pair walkers (MIRROR = 1: radial / simple_divisional, five planes, float4; every SLAT, both focal forms) hold two
+    # rows' loads: two waves per SIMD (256 VGPRs), and never a byte of scratch
+    pairs = {n: v for n, v in sweeps.items() if re.search(r"sweep_kernelILi[23]ELb1ELb1ELb1ELb[01]ELi4ELi[012]ELb1EEEv", n)}
+    assert len(pairs) == 12 and all(v["vgpr"] <= 256 and v["scratch"] == 0 and v["lds"] <= 384 for v in pairs.values()), pairs
+    assert not any(re.search(r"sweep_kernelILi[01]E\w*ELb1EEEv", n) for n in sweeps), "pinhole / simple_radial have no row-pair walker"
