@@ -767,7 +767,7 @@ int gclm_system(gclm_handle* h, const float* d_up, const float* d_lat, const flo
     DeviceGuard guard(h->device);
     GCLM_HIP(h, guard.status);
     const bool al = is_aligned16(d_up) && is_aligned16(d_lat) && is_aligned16(d_up_conf) && is_aligned16(d_lat_conf);
-    const Geometry geo = plan_geometry(B, H, W, al, h->sweep_iters, h->cfg.camera_model);
+    const Geometry geo = plan_sweeps(h, B, H, W, al, d_up && d_up_conf && d_lat_conf);
     SolveCtx& c = h->ctx;
     c.cfg = h->cfg;
     c.B = B; c.H = H; c.W = W; c.nchunks = geo.nchunks;

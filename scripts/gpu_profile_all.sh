@@ -8,7 +8,7 @@ S=scripts/gpu_profile.sh
 $S $TAG pinhole pinhole_B1024 1
 $S $TAG simple_radial simple_radial_B1024 1
 $S $TAG radial radial_B1024 0 --cpu-sample 0
-$S $TAG simple_divisional simple_divisional_B1024 0 --cpu-sample 0
+$S $TAG simple_divisional simple_divisional_B1024 1 --cpu-sample 0      # (PMC: the row-pair walk reads every byte once, too)
 $S $TAG pinhole shared16_pinhole 0 --shared-group 16 --cpu-sample 0
 $S $TAG simple_radial shared16_simple_radial 0 --shared-group 16 --cpu-sample 0
 $S $TAG pinhole pinhole_B8192 0 --batch 8192 --steps 3 --cpu-sample 0

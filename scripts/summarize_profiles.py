@@ -46,6 +46,12 @@ for i in (1, 2):
           f"{d['placement'].get('first_allocation')}, overlap {d['overlap']['value']:.0f} ({d['overlap']['bit_identical']}), simple_radial {sr['value']:.0f} "
           f"({sr['roofline']['frac']:.4f}), shared16 {s['shared16_pinhole']['value']:.0f} ({s['shared16_pinhole']['roofline']['frac']:.4f}), "
           f"cpu {d['cpu_baseline']['kind']} {d['cpu_baseline']['value']:.1f} img/s on {d['cpu_baseline']['cores']} cores")
+    sd = next((v for k, v in s.items() if k.startswith("simple_divisional")), None)
+    if sd:
+        rp, c = sd["row_pairs_off"], sd["check"]["vs_oracle"]
+        print(f"   simple_divisional {sd['value']:.0f} ({sd['roofline']['frac']:.4f}, {sd['roofline'].get('frac_of_read_ceiling')} of its read ceiling); one-row walk "
+              f"{rp['value']:.0f} ({rp['frac']:.4f}); row pairs again {rp['on_again']['frac']:.4f}; vs oracle {c['images_within_gate']} of {c['images']} within 1e-4, "
+              f"medians {c['median_focal_rel']:.1e} / {c['median_gravity_abs']:.1e} / {c['median_final_cost_rel']:.1e}")
 for m in ("pinhole", "simple_radial", "radial", "simple_divisional"):
     d = load(f"power_{m}.json")
     if d:

@@ -158,13 +158,19 @@ TOL_SYSTEM_DIV_K = 1e-3      # single-sweep system, simple_divisional, k row / c
 
 @pytest.mark.parametrize("model", ALL_MODELS)
 @pytest.mark.parametrize("mode", ["loop", "rpf"])
-def test_hip_single_sweep_system(dev, model, mode):
-    """gclm_system: costs, J^T W r, J^T W J of ONE fused sweep at fixed, non-converged parameters."""
+@pytest.mark.parametrize("row_pairs", [None, True])
+def test_hip_single_sweep_system(dev, model, mode, row_pairs):
+    """gclm_system: costs, J^T W r, J^T W J of ONE fused sweep at fixed, non-converged parameters against the reference's
+    setup_system (`row_pairs`: the same gates on the row-pair walk of the sweep, radial / simple_divisional)."""
     from geocalib_amd import Gravity, LMOptimizer, camera_models
+    if row_pairs and model not in ("radial", "simple_divisional"):
+        pytest.skip("the row-pair walk exists for radial / simple_divisional")
     s = np.load(os.path.join(GOLDEN, "golden_system.npz"))
     inp = np.load(os.path.join(GOLDEN, f"inputs_{model}.npz"))
     data = {k: inp[k] for k in ("up_field", "latitude_field", "up_confidence", "latitude_confidence")}
+    assert data["latitude_field"].shape[-2] % 2 == 0 and data["latitude_field"].shape[-1] % 4 == 0      # (pairs can be walked)
     opt = LMOptimizer({"camera_model": model}).eval()
+    opt.row_pairs = row_pairs
     cam = camera_models[model](torch.from_numpy(s[f"{model}/camera"]).to(dev))
     grav = Gravity(torch.from_numpy(s[f"{model}/gravity"]).to(dev))
     out = to_np(opt.system(to_dev(data, dev), cam, grav, as_rpf=(mode == "rpf")))
@@ -179,7 +185,7 @@ def test_hip_single_sweep_system(dev, model, mode):
     eh = (np.abs(out["H"] - Hr) / (d[:, :, None] * d[:, None, :])).max(0)
     cost = (s[f"{model}/{mode}/cost_up"] + s[f"{model}/{mode}/cost_lat"]) * data["latitude_field"][0].size
     eg = (np.abs(out["G"] - Gr) / (d * np.sqrt(cost)[:, None])).max(0)
-    MEASURED[f"system/{model}/{mode}"] = {"H_rows": eh.max(1).tolist(), "G": eg.tolist()}
+    MEASURED[f"system/{model}/{mode}" + ("/row_pairs" if row_pairs else "")] = {"H_rows": eh.max(1).tolist(), "G": eg.tolist()}
     assert (eh < np.maximum(tol[:, None], tol[None, :])).all(), eh
     assert (eg < tol).all(), eg
     assert np.allclose(out["cost_up"], s[f"{model}/{mode}/cost_up"], rtol=2e-5)
