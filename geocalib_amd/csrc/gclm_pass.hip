@@ -64,13 +64,16 @@
 #define GCLM_RADIAL_WAVES 3
 #endif
 #ifndef GCLM_MIRROR_MODELS
-#define GCLM_MIRROR_MODELS (1 << GCLM_SIMPLE_DIVISIONAL)   // models whose BUILT-IN choice is the row-pair walk (same-allocation A/B,
-                                                          // profiles/r06_variant_row_pairs.log: simple_divisional -14.2 % per sweep;
-                                                          // radial -1.9 %: has the instantiations, gclm_set_row_pairs(h, 1) picks them)
+#define GCLM_MIRROR_MODELS ((1 << GCLM_RADIAL) | (1 << GCLM_SIMPLE_DIVISIONAL))   // models whose BUILT-IN choice is the row-pair walk
+                             // (same-allocation A/B, profiles/r06_variant_row_pairs.log: simple_divisional -14.2 % per sweep at
+                             // 2 waves per SIMD; radial -3.9 % once its walker is held to 168 VGPRs = 3 waves, -1.3 % at 2)
 #endif
 #ifndef GCLM_MIRROR_WAVES
 #define GCLM_MIRROR_WAVES 2    // the row-pair walkers (sweep_body: MIRROR) hold two rows' loads: 256 VGPRs
 #endif
+#ifndef GCLM_MIRROR_WAVES_RADIAL
+#define GCLM_MIRROR_WAVES_RADIAL 3    // ... radial's log-focal walker fits 168 VGPRs = 3 waves (16-32 B of scratch: one 8-byte
+#endif                                //     reload per iteration); its general-focal form would spill 216-248 B there and keeps 2
 #ifndef GCLM_SLAT_PINHOLE
 #define GCLM_SLAT_PINHOLE 1    // pinhole has the scratch-plane instantiations too: never the built-in choice (memory-bound), only
 #endif                         // gclm_set_slat_plane(h, 1) launches them (measurement)
@@ -1030,7 +1033,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const PBlock& P, 
 // own; the log-focal pinhole sweep is held to 80 (6 waves); its general-focal instantiation would spill at 80 and keeps its own
 // 96, and so do its scratch-plane instantiations SLAT != 0 (never the library's built-in choice for pinhole)
 template <int MODEL, bool HAS_UP, bool HAS_UPC, bool HAS_LATC, bool LOGF, int VEC, int SLAT = 0, bool MIRROR = false>
-__global__ __launch_bounds__(kBlock, MIRROR ? GCLM_MIRROR_WAVES : (VEC == 4 && MODEL == GCLM_RADIAL) ? GCLM_RADIAL_WAVES : (VEC == 4 && MODEL > GCLM_RADIAL) ? GCLM_DIV_WAVES : (VEC == 4 && MODEL == GCLM_SIMPLE_RADIAL) ? 4 : (VEC == 4 && MODEL == GCLM_PINHOLE && LOGF) ? (SLAT == 0 ? GCLM_PINHOLE_WAVES : 5) : GCLM_MIN_WAVES) void sweep_kernel(
+__global__ __launch_bounds__(kBlock, MIRROR ? (MODEL == GCLM_RADIAL && LOGF ? GCLM_MIRROR_WAVES_RADIAL : GCLM_MIRROR_WAVES) : (VEC == 4 && MODEL == GCLM_RADIAL) ? GCLM_RADIAL_WAVES : (VEC == 4 && MODEL > GCLM_RADIAL) ? GCLM_DIV_WAVES : (VEC == 4 && MODEL == GCLM_SIMPLE_RADIAL) ? 4 : (VEC == 4 && MODEL == GCLM_PINHOLE && LOGF) ? (SLAT == 0 ? GCLM_PINHOLE_WAVES : 5) : GCLM_MIN_WAVES) void sweep_kernel(
     const SweepArgs a) {
     if (stop_fired_before(a.ctrl, a.stop_step)) return;   // batch-global early stop, no host sync
     const int b = blockIdx.y, chunk = blockIdx.x;

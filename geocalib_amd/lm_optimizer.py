@@ -295,8 +295,8 @@ class LMOptimizer(nn.Module):
 
     # Host-side knob without a reference counterpart (include/gclm.h: gclm_set_row_pairs).  The sweep of a radial model may
     # take row H - y along with row y and evaluate what depends on r^2 once for both (same per-pixel values, another order of
-    # additions: results equal the one-row walk's to float32 summation order).  None: the library decides (batches of
-    # simple_divisional images); False: never -- the one-row walk, bit for bit; True: wherever the sweep can (radial too).
+    # additions: results equal the one-row walk's to float32 summation order).  None: the library decides (batches of radial /
+    # simple_divisional images); False: never -- the one-row walk, bit for bit; True: wherever the sweep can (small launches too).
     row_pairs = None
 
     def _handle(self, device: torch.device, stream: int = None) -> _Handle:

@@ -43,7 +43,7 @@ extern "C" {
  * empty batch (B = 0, NULL fields) is accepted by gclm_solve / gclm_calibrate; 500 = round 5: gclm_set_slat_plane and gclm_plan_cut added;
  * 600 = round 6: gclm_set_slat_plane_limit, gclm_slat_plane_bytes, gclm_release_workspace and gclm_read_probe added, the
  * scratch plane became an optional allocation of its own, gclm_merge_stop_at skips empty parts; 610 = round 6: gclm_set_row_pairs
- * added -- simple_divisional batches walk row pairs by default, results equal the one-row walk's to summation order).  gclm_create refuses a gclm_config whose first two fields do not
+ * added -- radial / simple_divisional batches walk row pairs by default, results equal the one-row walk's to summation order).  gclm_create refuses a gclm_config whose first two fields do not
  * carry the library's own sizeof(gclm_config) and GCLM_VERSION, with a message naming both sides. */
 #define GCLM_VERSION 610
 
@@ -398,14 +398,14 @@ int gclm_set_slat_plane_limit(gclm_handle* h, size_t max_bytes);
 /* Row pairs (radial / simple_divisional).  Everything a radial camera model adds to the per-pixel work depends on
  * r2 = u^2 + v^2 only.  The principal point of every camera the library initialises is the image centre (camera.py:136-152),
  * so rows y and H - y of a column share r2 bit for bit; a lane of the sweep then takes row H - y along with row y and
- * evaluates the radial terms once for both (gclm_pass.hip: row_math_mirror; simple_divisional: -18 % arithmetic).  The
+ * evaluates the radial terms once for both (gclm_pass.hip: row_math_mirror; simple_divisional -14 % per sweep, radial -4 %).  The
  * per-pixel values are those of the one-row walk bit for bit; the order in which a lane adds its pixels differs, so results
  * agree with it to float32 summation order (~1e-7), not bit for bit.  An image whose principal point is NOT the centre
  * (an explicit camera handed to gclm_solve) is detected per image on the device and walks the same pairs without sharing.
  * mode -1 (default): the library decides (the models it pays for, all five planes on the 16-byte-aligned path, an even
  * number of rows, and more workgroups per launch than the one-launch-per-step path takes -- 768: below that a step is
  * latency-bound, and its two-launch form stays bit-identical to the one-launch form); 0: never (the one-row walk of every
- * earlier ABI, bit for bit); 1: wherever the sweep has the instantiation (radial too; also small launches, unless
+ * earlier ABI, bit for bit); 1: wherever the sweep has the instantiation (also small launches, unless
  * gclm_set_fused_steps(h, 1) asks for one launch per step as well). */
 int gclm_set_row_pairs(gclm_handle* h, int mode);
 

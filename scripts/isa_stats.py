@@ -58,6 +58,8 @@ def main():
         # common one is the loop with fewer v_cndmask; every other model has one big loop
         bigloops = [t for t in loops if t[1] - t[0] > 100] or loops
         a, b = min(bigloops, key=lambda t: sum("v_cndmask" in l for l in body[t[0]:t[1] + 1]))
+        if mirror:      # three row loops (unshared first iteration is straight-line; unshared loop; shared loop): the hot one is the shortest
+            a, b = min(bigloops, key=lambda t: sum(1 for l in body[t[0]:t[1] + 1] if l.startswith("\tv_")))
         other_loops = [sum(1 for l in body[t[0]:t[1] + 1] if l.startswith("\tv_")) for t in bigloops if t != (a, b)]
         # The loop holds side blocks that a wave only enters in rare cases: the latitude fold (|lat| > pi/2: marked by
         # v_rndne) and, for simple_divisional, the guarded copy of the body (the one of its two big blocks with MORE
@@ -93,7 +95,7 @@ def main():
                                 "vgprs": int(nv.group(1)) if nv else None, "scratch_bytes": int(sc.group(1)) if sc else None,
                                 "top": c.most_common(12)}
         print(f"{NAMES[m_id]}: loop {len(ops)} instr, VALU {valu} (packed {pk}, trans {trans}, mov {mov}), "
-              f"{loads} global loads, {mfma} mfma -> {valu / 4:.1f} VALU/px; rare blocks (VALU) {sorted(rare_valu.values())}, other loops {other_loops}; VGPRs {nv.group(1) if nv else '?'}, "
+              f"{loads} global loads, {mfma} mfma -> {valu / (8 if mirror else 4):.1f} VALU/px; rare blocks (VALU) {sorted(rare_valu.values())}, other loops {other_loops}; VGPRs {nv.group(1) if nv else '?'}, "
               f"scratch {sc.group(1) if sc else '?'} B")
         print("   ", c.most_common(12))
         if dump and dump in m.group(1):

@@ -2029,7 +2029,7 @@ def test_row_pairs_equal_the_one_row_walk_to_summation_order(dev, model):
       * where the sweep has no row-pair walker (odd height, a missing confidence, the scalar path) the knob changes nothing,
         bit for bit; mode 0 and the built-in choice on a small launch are the one-row walk, bit for bit;
       * the walk is deterministic (same call, same bits) and shard-invariant (images are independent);
-      * a full solve of a BATCH (the built-in choice for simple_divisional: > 768 workgroups) recovers the ground truth and
+      * a full solve of a BATCH (the built-in choice for both models: > 768 workgroups) recovers the ground truth and
         stays within the fuzz gate of the one-row solve on the well-conditioned images.
     The gates against the REFERENCE run on the row-pair walk in test_hip_matches_reference_small / _full_size_other_models."""
     from conftest import MEASURED, result_spread
@@ -2102,12 +2102,12 @@ def test_row_pairs_equal_the_one_row_walk_to_summation_order(dev, model):
                       "final_cost": info["final_cost"].cpu().numpy(), "initial_cost": info["initial_cost"].cpu().numpy()}
     assert (result_spread(res[True], res[False]) < 1e-5).all(), result_spread(res[True], res[False])
     assert np.array_equal(res[True]["camera"][:, 4:6], cam0[:, 4:6].cpu().numpy())
-    # a batch: the built-in choice pairs the rows of simple_divisional (not of radial), shards agree with the whole
+    # a batch: the built-in choice pairs the rows, shards agree with the whole
     B, H, W = 416, 480, 640          # (halves of 208 images: still cut into workgroups like the whole batch, plan_geometry)
     data, gt_cam, gt_grav = synth_device(model, B, H, W, dev, seed=12)
     conf = {"num_steps": 20, "early_stop": False}
     auto, on, off = solve(conf, data, None), solve(conf, data, True), solve(conf, data, False)
-    assert same_bits(auto, on if model == "simple_divisional" else off), "built-in choice"
+    assert same_bits(auto, on) and not same_bits(on, off), "built-in choice for a batch: row pairs (both models)"
     half = solve(conf, {k: v[B // 2:] for k, v in data.items()}, True)
     assert all(np.array_equal(half[k], on[k][B // 2:], equal_nan=True) for k in ("camera", "gravity", "final_cost", "covariance"))
     f_err = np.abs(on["camera"][:, 3] / gt_cam[:, 3].cpu().numpy() - 1)

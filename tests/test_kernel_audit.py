@@ -47,7 +47,7 @@ def test_no_sweep_kernel_carries_an_lds_array_or_scratch_it_was_not_given(tmp_pa
     # -- pinned by their exact template arguments <MODEL, HAS_UP, HAS_UPC, HAS_LATC, LOGF = 0, VEC = 4, SLAT, MIRROR = 0>, with the bytes each
     # may spill (a substring match plus a count would let any other instantiation start spilling unnoticed)
     spilling = {re.search(r"sweep_kernelI(\w+?)EEv|fused_step_kernelI(\w+?)EEv", n).group(0): v["scratch"]
-                for n, v in {**sweeps, **fused}.items() if v["scratch"]}
+                for n, v in {**sweeps, **fused}.items() if v["scratch"] and "ELb1EEEv" not in n}   # (MIRROR = 1, the row pairs: below)
     allowed = {"sweep_kernelILi3ELb1ELb0ELb1ELb0ELi4ELi0ELb0EEEv": 8,      # simple_divisional, no up confidence, general focal
                "sweep_kernelILi3ELb1ELb1ELb1ELb0ELi4ELi0ELb0EEEv": 16,     # simple_divisional, five planes, general focal
                "sweep_kernelILi2ELb1ELb1ELb1ELb0ELi4ELi2ELb0EEEv": 8}      # radial, scratch-plane reader, general focal
@@ -63,7 +63,13 @@ def test_no_sweep_kernel_carries_an_lds_array_or_scratch_it_was_not_given(tmp_pa
             assert inst[0]["vgpr"] <= 96 and inst[1]["vgpr"] <= 128 and inst[2]["vgpr"] <= 168 and inst[3]["vgpr"] <= 168, (slat, logf, inst)
             assert all(v["scratch"] == 0 for m, v in inst.items() if logf == 1), (slat, logf, inst)
     # the row-pair walkers (MIRROR = 1: radial / simple_divisional, five planes, float4; every SLAT, both focal forms) hold two
-    # rows' loads: two waves per SIMD (256 VGPRs), and never a byte of scratch
+    # rows' loads.  simple_divisional: two waves per SIMD (256 VGPRs), never a byte of scratch (held to 168 it spills 276 B and
+    # runs 41 % slower, profiles/r06_variant_row_pairs.log).  radial, log-focal (every loop sweep of the default conf): held to
+    # 168 VGPRs = three waves, which is what makes its row pairs pay (-3.9 % against -1.3 % at two waves); 16-32 B of scratch, one
+    # 8-byte reload per iteration of the hot loop.  radial, general focal: two waves, no scratch (216-248 B at 168)
     pairs = {n: v for n, v in sweeps.items() if re.search(r"sweep_kernelILi[23]ELb1ELb1ELb1ELb[01]ELi4ELi[012]ELb1EEEv", n)}
-    assert len(pairs) == 12 and all(v["vgpr"] <= 256 and v["scratch"] == 0 and v["lds"] <= 384 for v in pairs.values()), pairs
+    assert len(pairs) == 12 and all(v["lds"] <= 384 for v in pairs.values()), pairs
+    assert all(v["vgpr"] <= 256 and v["scratch"] == 0 for n, v in pairs.items() if "ILi3E" in n), pairs
+    assert all(v["vgpr"] <= 168 and v["scratch"] <= 48 for n, v in pairs.items() if "ILi2ELb1ELb1ELb1ELb1E" in n), pairs
+    assert all(v["vgpr"] <= 256 and v["scratch"] == 0 for n, v in pairs.items() if "ILi2ELb1ELb1ELb1ELb0E" in n), pairs
     assert not any(re.search(r"sweep_kernelILi[01]E\w*ELb1EEEv", n) for n in sweeps), "pinhole / simple_radial have no row-pair walker"
