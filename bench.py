@@ -130,7 +130,7 @@ def vs_oracle(hip, ref, what):
             "against": "oracle/lm_oracle.c (float32), " + what}
 
 
-def oracle_solve(model, lm_steps, data, group, cores):
+def oracle_solve(model, lm_steps, data, group, cores, precision="f32"):
     """The checker's answer on `data` (numpy, float32): oracle/lm_oracle.c at float32, independent images, or -- `group` > 0 --
     shared-intrinsics groups of `group` frames, ONE group per call as the reference solves them (lm_optimizer.py:350-383)."""
     import numpy as np
@@ -138,10 +138,10 @@ def oracle_solve(model, lm_steps, data, group, cores):
     conf = {"camera_model": model, "num_steps": lm_steps, "early_stop": False}
     n = next(iter(data.values())).shape[0]
     if group:
-        outs = [lm_oracle.solve({k: v[lo:lo + group] for k, v in data.items()}, {**conf, "shared_intrinsics": True}, precision="f32",
+        outs = [lm_oracle.solve({k: v[lo:lo + group] for k, v in data.items()}, {**conf, "shared_intrinsics": True}, precision=precision,
                                 num_threads=cores) for lo in range(0, n, group)]
     else:
-        outs = [lm_oracle.solve(data, conf, precision="f32", num_threads=cores)]
+        outs = [lm_oracle.solve(data, conf, precision=precision, num_threads=cores)]
     return {k: np.concatenate([o[k] for o in outs]) for k in ("camera", "gravity", "final_cost")}
 
 
@@ -367,9 +367,30 @@ def quick_case(lib, LMOptimizer, synth_fields, dev, model, B, H, W, lm_steps, se
             if group:
                 n = max(group, n // group * group)
             host = {k: v[:n].cpu().numpy() for k, v in data.items()}
-            rec["check"]["vs_oracle"] = vs_oracle(hip_rows(out, n), oracle_solve(model, lm_steps, host, group, effective_cpus()),
+            ref32 = oracle_solve(model, lm_steps, host, group, effective_cpus())
+            rec["check"]["vs_oracle"] = vs_oracle(hip_rows(out, n), ref32,
                                                   f"the first {n} images of this case's timed batch" +
                                                   (f" as {n // group} shared-intrinsics groups of {group}" if group else ""))
+            if model == "simple_divisional":
+                # How sharp is the yardstick on these images?  The model's k column cancels in float32 (camera.py:913): the SAME
+                # algorithm evaluated in float64 lands elsewhere on some images.  An image counts as explained when the HIP
+                # result is within 1e-4 + 10 x that distance of the float32 oracle (the rule of the seeded fuzz, tests/).
+                import numpy as np
+                ref64 = oracle_solve(model, lm_steps, host, group, effective_cpus(), precision="f64")
+                hip = hip_rows(out, n)
+                def per_image(a, b):
+                    return np.maximum.reduce([np.abs(a["camera"][:n, 2:4] / b["camera"][:n, 2:4] - 1).max(1),
+                                              np.abs(a["gravity"][:n] - b["gravity"][:n]).max(1),
+                                              np.abs(a["final_cost"][:n] / b["final_cost"][:n] - 1)])
+                own, dist = per_image(ref32, ref64), per_image(hip, ref32)
+                beyond = dist > ORACLE_GATE
+                rec["check"]["vs_oracle"]["yardstick"] = {
+                    "what": "oracle/lm_oracle.c float32 against its own float64 build on the same images (largest of focal rel / "
+                            "gravity abs / final-cost rel per image): how far two evaluations of the reference ALGORITHM land apart",
+                    "images_where_it_exceeds_gate": int((own > ORACLE_GATE).sum()), "max": float(own.max()), "median": float(np.median(own)),
+                    "hip_beyond_gate": [{"image": int(i), "hip_vs_oracle32": float(dist[i]), "oracle32_vs_oracle64": float(own[i])}
+                                        for i in np.nonzero(beyond)[0][:8]],
+                    "images_within_gate_plus_10x_own": int((dist <= ORACLE_GATE + 10.0 * own).sum())}
         except Exception as e:          # the checker must never take the product measurement down
             rec["check"]["vs_oracle"] = {"error": repr(e)}
     del data, out

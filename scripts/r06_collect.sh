@@ -30,9 +30,11 @@ print("       simple_radial %.0f (%.4f; plane off %.4f, on again %.4f, bits %s; 
     sr["value"], sr["roofline"]["frac"], sr["slat_off"]["frac"], sr["slat_off"]["on_again"]["frac"], sr["slat_off"]["bit_identical"], sr["roofline"]["frac_of_read_ceiling"], vo(sr["check"]["vs_oracle"]),
     sh["value"], sh["roofline"]["frac"], sh["roofline"]["frac_of_read_ceiling"], vo(sh["check"]["vs_oracle"]), d["cpu_baseline"]["kind"], d["cpu_baseline"]["value"]))
 sd = s["simple_divisional_B1024"]; rp = sd["row_pairs_off"]; c = sd["check"]["vs_oracle"]
-print("       simple_divisional %.0f (%.4f; one-row walk %.0f / %.4f, row pairs again %.4f; vs oracle: %d of %d images within 1e-4, medians %.1e/%.1e/%.1e, worst %.1e/%.1e/%.1e)" % (
+ys = c.get("yardstick", {})
+print("       simple_divisional %.0f (%.4f; one-row walk %.0f / %.4f, row pairs again %.4f; vs oracle: %d of %d images within 1e-4, medians %.1e/%.1e/%.1e, worst %.1e/%.1e/%.1e; the oracle's own float32 vs float64 exceeds 1e-4 on %s images, %s of %d within 1e-4 + 10 x that)" % (
     sd["value"], sd["roofline"]["frac"], rp["value"], rp["frac"], rp["on_again"]["frac"], c["images_within_gate"], c["images"],
-    c["median_focal_rel"], c["median_gravity_abs"], c["median_final_cost_rel"], c["max_focal_rel"], c["max_gravity_abs"], c["max_final_cost_rel"]))
+    c["median_focal_rel"], c["median_gravity_abs"], c["median_final_cost_rel"], c["max_focal_rel"], c["max_gravity_abs"], c["max_final_cost_rel"],
+    ys.get("images_where_it_exceeds_gate"), ys.get("images_within_gate_plus_10x_own"), c["images"]))
 PY
 done
 echo "=== bench.py --gpus 2 without a launcher (two gloo ranks sharing this GPU), image sharding and the frame split"

@@ -1424,6 +1424,10 @@ def test_bench_single_gpu_line_carries_secondary_overlap_and_best_of_n(dev):
             # the model's k column cancels in float32 (camera.py:913; the reference itself moves by 3e-4 under 1-ulp inputs,
             # tests/golden/make_golden_div_small.py): the record states how many of the 64 images sit within 1e-4 and the medians
             assert vo["images_within_gate"] >= 48 and max(vo["median_focal_rel"], vo["median_gravity_abs"], vo["median_final_cost_rel"]) <= 1e-4, vo
+            # ... and how sharp the yardstick is there: every image is within 1e-4 + 10 x (oracle float32 vs its float64 build)
+            ys = vo["yardstick"]
+            assert ys["images_within_gate_plus_10x_own"] == 64 and ys["images_where_it_exceeds_gate"] >= 64 - vo["images_within_gate"], ys
+            assert all(b["hip_vs_oracle32"] <= 1e-4 + 10 * b["oracle32_vs_oracle64"] for b in ys["hip_beyond_gate"]), ys
         else:
             assert vo["within_gate"] is True and vo["images_within_gate"] == 64, vo
             assert max(vo["max_focal_rel"], vo["max_gravity_abs"], vo["max_final_cost_rel"]) <= 1e-4
