@@ -865,15 +865,17 @@ __device__ __forceinline__ void row_math(const PBlock& P, const HuberK& hk, cons
 }
 
 // MIRROR (radial / simple_divisional, float4 path, five planes, even H) -- ROW PAIRS.  Everything a radial model adds to the
-// pixel body is a function of r2 = u^2 + v^2 alone: the radial terms (simple_divisional: ~165 of its 415 VALU instructions per
-// 4 pixels), |ray|^2 and its rsq.  The principal point of every camera the library initialises is the image centre
-// (camera.py:136-152), so rows y and H - y of a column have v' = -v EXACTLY (integer pixel coordinates, cy = H / 2) and the
-// same r2 bit for bit.  A lane therefore walks the upper half of its column and takes row H - y along with row y: the second
-// row's body is the same inlined pixel code called with -v, and the compiler's value numbering merges every expression that
-// depends on (u, v^2) only -- same operations on the same values, hence the same per-pixel bits as the one-row walker; only
-// the order in which a lane adds its pixels changes.  Row 0 has no mirror image and row H / 2 is its own: they pair up with
-// each other WITHOUT sharing (wave-uniform `share`, false in the one iteration that holds row 0 and for an image whose
-// principal point is not the centre -- an explicit camera: the second row then gets its own v and its own radial terms).
+// pixel body is a function of r2 = u^2 + v^2 alone: the radial terms (simple_divisional: ~165 of its 417 VALU instructions per
+// 4 pixels; radial: ~35 of 305), |ray|^2 and its rsq.  The principal point of every camera the library initialises is the
+// image centre (camera.py:136-152), so rows y and H - y of a column have v' = -v EXACTLY (integer pixel coordinates,
+// cy = H / 2) and the same r2 bit for bit.  A lane therefore walks the upper half of its column and takes row H - y along
+// with row y: pixel_shared is evaluated ONCE, pixel_stage twice, the second time with -v (what pixel_stage derives from r2
+// alone -- tau r2, |ray|^2, its rsq -- is the same expression on the same values in both calls and is merged by the
+// compiler's value numbering).  Same operations on the same values, hence the same per-pixel bits as the one-row walker;
+// only the order in which a lane adds its pixels changes.
+// SHARE = false: the pair is walked WITHOUT sharing -- the second row gets its own v and its own pixel_shared.  For the one
+// iteration that holds row 0 (row 0 has no mirror image and row H / 2 is its own: they pair up with each other) and for an
+// image whose principal point is not the centre (an explicit camera, `scales`); sweep_body picks the copy, wave-uniformly.
 template <int MODEL, bool HAS_UP, bool LOGF, int VEC, int SLAT, bool SHARE>
 __device__ __forceinline__ void row_math_mirror(const PBlock& P, const HuberK& hk, const typename Lane<VEC>::F (&col_u)[Lane<VEC>::kPairs],
                                                 const typename Lane<VEC>::F (&col_px)[Lane<VEC>::kPairs], const int y, const int y2,
