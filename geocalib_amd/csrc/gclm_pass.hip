@@ -63,6 +63,9 @@
 #ifndef GCLM_RADIAL_WAVES
 #define GCLM_RADIAL_WAVES 3
 #endif
+#ifndef GCLM_LAT_PAIRS
+#define GCLM_LAT_PAIRS 1       // row pairs, log-focal: the latitude sums of the two rows are taken together (lat_pair_accumulate)
+#endif
 #ifndef GCLM_MIRROR_MODELS
 #define GCLM_MIRROR_MODELS ((1 << GCLM_RADIAL) | (1 << GCLM_SIMPLE_DIVISIONAL))   // models whose BUILT-IN choice is the row-pair walk
                              // (same-allocation A/B, profiles/r06_variant_row_pairs.log: simple_divisional -14.2 % per sweep at
@@ -502,10 +505,19 @@ __device__ __forceinline__ void pixel_shared(const PBlock& P, F u, float v, [[ma
     }
 }
 
-template <int MODEL, bool HAS_UP, bool LOGF, typename F, int EMIT = 0>
+// What the latitude field of one row hands to lat_pair_accumulate (row pairs): Huber weight x confidence, residual, the two
+// gravity columns, and h.uv -- every other latitude column is (a function of r2) x h.uv
+template <typename F>
+struct LatRow {
+    F wgt, rl, l0, l1, hu;
+};
+// PART: 0 = both fields, 1 = the up field only, 2 = the latitude field only (the row-pair walker orders them itself);
+// EMIT = 3 (with PART 2): the latitude terms go to `lat_out` instead of into the sums
+template <int MODEL, bool HAS_UP, bool LOGF, typename F, int EMIT = 0, int PART = 0>
 __device__ __forceinline__ void pixel_stage(const PBlock& P, const HuberK& hk, const PixelShared<MODEL, F>& S, F u, F px, float v,
                                             F dux, F duy, F slat, F cu, F cl, F (&acc)[Layout<MODEL>::NACC],
-                                            [[maybe_unused]] float* j_up = nullptr, [[maybe_unused]] float* j_lat = nullptr) {
+                                            [[maybe_unused]] float* j_up = nullptr, [[maybe_unused]] float* j_lat = nullptr,
+                                            [[maybe_unused]] LatRow<F>* lat_out = nullptr) {
     constexpr bool DIST = MODEL != GCLM_PINHOLE;
     constexpr int ND = Layout<MODEL>::ND, PN = Layout<MODEL>::PN;
     const F r2 = S.r2;
@@ -518,7 +530,7 @@ __device__ __forceinline__ void pixel_stage(const PBlock& P, const HuberK& hk, c
         wy = -v * P.wfy;
     }
 
-    if constexpr (HAS_UP) {
+    if constexpr (HAS_UP && PART != 2) {
         const float py = fmaf(-P.gc, v, P.gb);
         F qx = px, qy = vsplat(u, py), t = vsplat(u, 0.f);
         if constexpr (DIST) {
@@ -603,7 +615,8 @@ __device__ __forceinline__ void pixel_stage(const PBlock& P, const HuberK& hk, c
         }
     }
 
-    {   // latitude (ray = (tau u, tau v, 1)/n only through dot products, see pixel_accumulate_fast; the explicit-ray form
+    if constexpr (PART != 1) {
+        // latitude (ray = (tau u, tau v, 1)/n only through dot products, see pixel_accumulate_fast; the explicit-ray form
         // measured 1.5-3 % slower for every model: profiles/README.md)
         const F tr2 = DIST ? R.tau * r2 : r2;
         const F nn = DIST ? vfma(R.tau, tr2, vsplat(u, 1.0f)) : r2 + 1.0f;
@@ -629,6 +642,11 @@ __device__ __forceinline__ void pixel_stage(const PBlock& P, const HuberK& hk, c
         //   h.uv = rnn (g_xy.uv - s trn r2),   h.w = rnn (g_xy.w - s trn (uv.w))
         [[maybe_unused]] F hu = vsplat(u, 0.f);
         if constexpr (LOGF || DIST) hu = vfma(-s_, tr2 * rnn, guv) * rnn;
+        if constexpr (EMIT == 3) {
+            static_assert(LOGF && DIST && PART == 2, "latitude terms out: the log-focal row-pair walker");
+            lat_out->wgt = wgt; lat_out->rl = rl; lat_out->l0 = l[0]; lat_out->l1 = l[1]; lat_out->hu = hu;
+            return;
+        }
         if constexpr (LOGF) {                            // h.w = -h.uv, uv.w = -r2
             l[2] = -hu;
             if constexpr (DIST) l[2] = -(hu * vfma(R.tau1x2, r2, R.tau));
@@ -652,6 +670,45 @@ __device__ __forceinline__ void pixel_stage(const PBlock& P, const HuberK& hk, c
         } else {
             accumulate<MODEL>(acc, l, wgt, rl);
         }
+    }
+}
+
+// ROW PAIRS, log-focal: the latitude sums of rows y and H - y of a pixel pair taken TOGETHER.  Every latitude column but the two
+// gravity columns is f_j(r2) h.uv with f_2 = -(tau + 2 tau1 r2), f_{3+j} = dtau/dk_j (pixel_stage) -- functions of r2 that the
+// two rows share -- so with a_r = w_r hu_r:
+//   sum_r w_r l_j l_k = (sum_r a_r hu_r) f_j f_k,   sum_r w_r l_i l_j = (sum_r a_r l_i) f_j (i < 2),   sum_r w_r rl l_j = (sum_r a_r rl_r) f_j
+// 45 instead of 56 packed operations per pixel pair for radial (36 instead of 40 for simple_divisional); the sums differ from
+// the row-by-row form in their rounding only.
+template <int MODEL, typename F>
+__device__ __forceinline__ void lat_pair_accumulate(F (&acc)[Layout<MODEL>::NACC], const PixelShared<MODEL, F>& S, const LatRow<F>& A,
+                                                    const LatRow<F>& B) {
+    constexpr int PM = Layout<MODEL>::PM, ND = Layout<MODEL>::ND;
+    const Radial<F>& R = S.R;
+    F f[1 + ND];
+    f[0] = -vfma(R.tau1x2, S.r2, R.tau);
+#pragma unroll
+    for (int j = 0; j < ND; ++j) f[1 + j] = R.dtau[j];
+    // the gravity columns, row by row
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const LatRow<F>& L = r == 0 ? A : B;
+        const F w0 = L.wgt * L.l0, w1 = L.wgt * L.l1;
+        acc[A_G0 + 0] = vfma(w0, L.rl, acc[A_G0 + 0]);
+        acc[A_G0 + 1] = vfma(w1, L.rl, acc[A_G0 + 1]);
+        acc[acc_h(PM, 0, 0)] = vfma(w0, L.l0, acc[acc_h(PM, 0, 0)]);
+        acc[acc_h(PM, 0, 1)] = vfma(w0, L.l1, acc[acc_h(PM, 0, 1)]);
+        acc[acc_h(PM, 1, 1)] = vfma(w1, L.l1, acc[acc_h(PM, 1, 1)]);
+    }
+    const F a1 = A.wgt * A.hu, a2 = B.wgt * B.hu;
+    const F sAA = vfma(a2, B.hu, a1 * A.hu), sC = vfma(a2, B.rl, a1 * A.rl);
+    const F sB0 = vfma(a2, B.l0, a1 * A.l0), sB1 = vfma(a2, B.l1, a1 * A.l1);
+#pragma unroll
+    for (int m = 0; m <= ND; ++m) {
+        acc[A_G0 + 2 + m] = vfma(sC, f[m], acc[A_G0 + 2 + m]);
+        acc[acc_h(PM, 0, 2 + m)] = vfma(sB0, f[m], acc[acc_h(PM, 0, 2 + m)]);
+        acc[acc_h(PM, 1, 2 + m)] = vfma(sB1, f[m], acc[acc_h(PM, 1, 2 + m)]);
+#pragma unroll
+        for (int n = m; n <= ND; ++n) acc[acc_h(PM, 2 + m, 2 + n)] = vfma(sAA, f[m] * f[n], acc[acc_h(PM, 2 + m, 2 + n)]);
     }
 }
 
@@ -895,11 +952,25 @@ __device__ __forceinline__ void row_math_mirror(const PBlock& P, const HuberK& h
     for (int k = 0; k < L::kPairs; ++k) {
         PixelShared<MODEL, F> S;
         pixel_shared<MODEL, LOGF, F, GM>(P, col_u[k], v, patch, S);
+        if constexpr (SHARE && LOGF && GCLM_LAT_PAIRS) {
+            // both up fields, then both latitude fields with their sums taken together (lat_pair_accumulate)
+            pixel_stage<MODEL, HAS_UP, LOGF, F, 0, 1>(P, hk, S, col_u[k], col_px[k], v, L::get(r.vux, k), L::get(r.vuy, k), slat[k],
+                                                      L::get(r.vcu, k), L::get(r.vcl, k), acc);
+            pixel_stage<MODEL, HAS_UP, LOGF, F, 0, 1>(P, hk, S, col_u[k], col_px[k], v2, L::get(rm.vux, k), L::get(rm.vuy, k), slat2[k],
+                                                      L::get(rm.vcu, k), L::get(rm.vcl, k), acc);
+            LatRow<F> la, lb;
+            pixel_stage<MODEL, HAS_UP, LOGF, F, 3, 2>(P, hk, S, col_u[k], col_px[k], v, L::get(r.vux, k), L::get(r.vuy, k), slat[k],
+                                                      L::get(r.vcu, k), L::get(r.vcl, k), acc, nullptr, nullptr, &la);
+            pixel_stage<MODEL, HAS_UP, LOGF, F, 3, 2>(P, hk, S, col_u[k], col_px[k], v2, L::get(rm.vux, k), L::get(rm.vuy, k), slat2[k],
+                                                      L::get(rm.vcu, k), L::get(rm.vcl, k), acc, nullptr, nullptr, &lb);
+            lat_pair_accumulate<MODEL, F>(acc, S, la, lb);
+        } else {
         pixel_stage<MODEL, HAS_UP, LOGF, F>(P, hk, S, col_u[k], col_px[k], v, L::get(r.vux, k), L::get(r.vuy, k), slat[k],
                                             L::get(r.vcu, k), L::get(r.vcl, k), acc);
         if constexpr (!SHARE) pixel_shared<MODEL, LOGF, F, GM>(P, col_u[k], v2, patch, S);
         pixel_stage<MODEL, HAS_UP, LOGF, F>(P, hk, S, col_u[k], col_px[k], v2, L::get(rm.vux, k), L::get(rm.vuy, k), slat2[k],
                                             L::get(rm.vcu, k), L::get(rm.vcl, k), acc);
+        }
     }
 }
 
