@@ -63,6 +63,15 @@
 #ifndef GCLM_RADIAL_WAVES
 #define GCLM_RADIAL_WAVES 3
 #endif
+#ifndef GCLM_PINHOLE_LDS
+#define GCLM_PINHOLE_LDS 51200 // dynamic LDS bytes of pinhole's float4 sweep launches = THREE workgroups per CU = 3 waves per SIMD where its
+#endif                         // 80 VGPRs allow 6: nothing is stored there -- the memory system streams better under fewer concurrent
+                               // waves (the no-math build: 6.89 TB/s at 6-8 waves, 6.97 at 3, 7.03 at 2, r06_variant_occupancy.log) and
+                               // pinhole's arithmetic still hides at 3 (-0.7 ... -1.9 % per sweep on six allocations of three boxes; 2
+                               // waves +1.4 %, simple_radial 4 -> 3 +0.6 ... +1.9 %: r06_variant_occupancy_{math,pinhole}.log).  Same bits.
+#ifndef GCLM_DYN_LDS
+#define GCLM_DYN_LDS 0         // measurement only: dynamic LDS bytes of a sweep launch, i.e. a cap on the workgroups per CU (with GCLM_NOMATH:
+#endif                         // what the access pattern streams at 2 ... 8 waves per SIMD, profiles/r06_variant_occupancy.log)
 #ifndef GCLM_LAT_PAIRS
 #define GCLM_LAT_PAIRS 1       // row pairs, log-focal: the latitude sums of the two rows are taken together (lat_pair_accumulate)
 #endif
@@ -1412,10 +1421,12 @@ hipError_t dispatch(const SweepArgs& a, hipStream_t s) {
     const bool up = a.up != nullptr, upc = up && a.upc != nullptr, latc = a.latc != nullptr;
     // the log-focal specialisation only for the vector path (the scalar path is the odd-shape fallback)
     const bool logf = VEC == 4 && a.log_focal != 0;
+    // an occupancy cap by LDS reservation for the memory-bound model (GCLM_PINHOLE_LDS above)
+    constexpr unsigned lds = (MODEL == GCLM_PINHOLE && VEC == 4 && GCLM_DYN_LDS == 0) ? GCLM_PINHOLE_LDS : GCLM_DYN_LDS;
 #define GCLM_LAUNCH(U, UC, LC)                                                                          \
     do {                                                                                                \
-        if (logf) hipLaunchKernelGGL((sweep_kernel<MODEL, U, UC, LC, VEC == 4, VEC>), grid, block, 0, s, a); \
-        else hipLaunchKernelGGL((sweep_kernel<MODEL, U, UC, LC, false, VEC>), grid, block, 0, s, a);    \
+        if (logf) hipLaunchKernelGGL((sweep_kernel<MODEL, U, UC, LC, VEC == 4, VEC>), grid, block, lds, s, a); \
+        else hipLaunchKernelGGL((sweep_kernel<MODEL, U, UC, LC, false, VEC>), grid, block, lds, s, a);    \
     } while (0)
     // row pairs (sweep_body: MIRROR): the five-plane float4 sweeps of radial / simple_divisional over an even number of rows
     if (a.mirror != 0) {
@@ -1425,9 +1436,9 @@ hipError_t dispatch(const SweepArgs& a, hipStream_t s) {
                 return hipErrorInvalidValue;
 #define GCLM_LAUNCH_MIRROR(LF)                                                                                              \
     do {                                                                                                                    \
-        if (a.slat_mode == 0) hipLaunchKernelGGL((sweep_kernel<MODEL, true, true, true, LF, 4, 0, true>), grid, block, 0, s, a);      \
-        else if (a.slat_mode == 1) hipLaunchKernelGGL((sweep_kernel<MODEL, true, true, true, LF, 4, 1, true>), grid, block, 0, s, a); \
-        else hipLaunchKernelGGL((sweep_kernel<MODEL, true, true, true, LF, 4, 2, true>), grid, block, 0, s, a);             \
+        if (a.slat_mode == 0) hipLaunchKernelGGL((sweep_kernel<MODEL, true, true, true, LF, 4, 0, true>), grid, block, GCLM_DYN_LDS, s, a);      \
+        else if (a.slat_mode == 1) hipLaunchKernelGGL((sweep_kernel<MODEL, true, true, true, LF, 4, 1, true>), grid, block, GCLM_DYN_LDS, s, a); \
+        else hipLaunchKernelGGL((sweep_kernel<MODEL, true, true, true, LF, 4, 2, true>), grid, block, GCLM_DYN_LDS, s, a);             \
     } while (0)
             if (logf) GCLM_LAUNCH_MIRROR(true); else GCLM_LAUNCH_MIRROR(false);
 #undef GCLM_LAUNCH_MIRROR
@@ -1442,8 +1453,8 @@ hipError_t dispatch(const SweepArgs& a, hipStream_t s) {
             if (!(up && upc && latc) || a.slat == nullptr || a.slat_mode < 0 || a.slat_mode > 2) return hipErrorInvalidValue;
 #define GCLM_LAUNCH_SLAT(LF)                                                                                         \
     do {                                                                                                             \
-        if (a.slat_mode == 1) hipLaunchKernelGGL((sweep_kernel<MODEL, true, true, true, LF, 4, 1>), grid, block, 0, s, a); \
-        else hipLaunchKernelGGL((sweep_kernel<MODEL, true, true, true, LF, 4, 2>), grid, block, 0, s, a);            \
+        if (a.slat_mode == 1) hipLaunchKernelGGL((sweep_kernel<MODEL, true, true, true, LF, 4, 1>), grid, block, GCLM_DYN_LDS, s, a); \
+        else hipLaunchKernelGGL((sweep_kernel<MODEL, true, true, true, LF, 4, 2>), grid, block, GCLM_DYN_LDS, s, a);            \
     } while (0)
             if (logf) GCLM_LAUNCH_SLAT(true); else GCLM_LAUNCH_SLAT(false);
 #undef GCLM_LAUNCH_SLAT

@@ -26,14 +26,14 @@ __global__ __launch_bounds__(256) void k_read(Planes pl, size_t units, float* si
     if (acc.x + acc.y + acc.z + acc.w == 1.2345e30f) sink[0] = acc.x;
 }
 template <int UNR, bool NT>
-void run(const char* name, Planes pl, size_t units, float* sink, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+void run(const char* name, Planes pl, size_t units, float* sink, hipStream_t s, hipEvent_t e0, hipEvent_t e1, unsigned lds = 0) {   // lds: dynamic LDS bytes = a cap on the workgroups per CU
     const dim3 grid((unsigned)((units + 256 * UNR - 1) / (256 * UNR)));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k_read<UNR, NT>), grid, dim3(256), 0, s, pl, units, sink);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k_read<UNR, NT>), grid, dim3(256), lds, s, pl, units, sink);
     CK(hipStreamSynchronize(s));
     float sum = 0, best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0, s));
-        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((k_read<UNR, NT>), grid, dim3(256), 0, s, pl, units, sink);
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((k_read<UNR, NT>), grid, dim3(256), lds, s, pl, units, sink);
         CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10; sum += ms; if (ms < best) best = ms;
     }
@@ -54,6 +54,9 @@ int main() {
         run<1, false>("1 unit / thread, plain", pl, units, sink, s, e0, e1);
         run<2, true>("2 units / thread, nt", pl, units, sink, s, e0, e1);
         run<4, true>("4 units / thread, nt", pl, units, sink, s, e0, e1);
+        run<4, true>("4 units, nt, 4 WG / CU", pl, units, sink, s, e0, e1, 40000);
+        run<4, true>("4 units, nt, 3 WG / CU", pl, units, sink, s, e0, e1, 51200);
+        run<4, true>("4 units, nt, 2 WG / CU", pl, units, sink, s, e0, e1, 80000);
         run<8, true>("8 units / thread, nt", pl, units, sink, s, e0, e1);
         run<20, true>("20 units / thread, nt", pl, units, sink, s, e0, e1);
         run<40, true>("40 units / thread, nt", pl, units, sink, s, e0, e1);
