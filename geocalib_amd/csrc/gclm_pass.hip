@@ -63,6 +63,9 @@
 #ifndef GCLM_RADIAL_WAVES
 #define GCLM_RADIAL_WAVES 3
 #endif
+#ifndef GCLM_REUSE_TNUV
+#define GCLM_REUSE_TNUV 1      // radial / simple_divisional, log-focal: the distortion columns of the up field reuse t (n.uv) and
+#endif                         // r2 (n.p) + 2 t (n.uv), which the focal column has formed (3 / 1 packed operations per pixel pair less)
 #ifndef GCLM_PINHOLE_LDS
 #define GCLM_PINHOLE_LDS 51200 // dynamic LDS bytes of pinhole's float4 sweep launches = THREE workgroups per CU = 3 waves per SIMD where its
 #endif                         // 80 VGPRs allow 6: nothing is stored there -- the memory system streams better under fewer concurrent
@@ -575,13 +578,16 @@ __device__ __forceinline__ void pixel_stage(const PBlock& P, const HuberK& hk, c
         if constexpr (DIST) {
             const F np_ = vfma(nx, px, ny * py);
             // + [p (off.w) + off (p.w)] . nq + t (Joff w) . nq            (perspective_fields.py:146-153)
+            [[maybe_unused]] F b_ = vsplat(u, 0.f), ab2 = vsplat(u, 0.f);
             if constexpr (LOGF) {                                // uv.w = -r2, n.w = -n.uv, p.w = -t
-                const F a_ = np_ * r2, b_ = t * nuv;
+                const F a_ = np_ * r2;
+                b_ = t * nuv;
                 if constexpr (MODEL == GCLM_SIMPLE_DIVISIONAL) {
                     s[2] = vfma(-R.s1x2, a_ + b_, s[2]);
                     s[2] = vfma(-b_, vfma(R.s2x4, r2, R.jd), s[2]);
                 } else {
-                    s[2] = vfma(-R.s1x2, vfma(b_, vsplat(u, 2.0f), a_), s[2]);
+                    ab2 = vfma(b_, vsplat(u, 2.0f), a_);         // r2 (n.p) + 2 t (n.uv) = dq/dk1 . nq as well (below)
+                    s[2] = vfma(-R.s1x2, ab2, s[2]);
                     if constexpr (MODEL == GCLM_RADIAL) s[2] = vfma(-(R.s2x4 * r2), b_, s[2]);
                 }
             } else {
@@ -596,13 +602,20 @@ __device__ __forceinline__ void pixel_stage(const PBlock& P, const HuberK& hk, c
             }
             if constexpr (MODEL == GCLM_RADIAL) {
                 // dq/dk1 = r2 p + 2 t uv,  dq/dk2 = r4 p + 4 r2 t uv = r2 (dq/dk1 + 2 t uv)                 (:170-180)
-                const F tn2 = (t * 2.0f) * nuv;
-                s[3] = vfma(r2, np_, tn2);
-                s[4] = r2 * (s[3] + tn2);
+                if constexpr (LOGF && GCLM_REUSE_TNUV) {         // the focal column has formed r2 (n.p) + 2 t (n.uv) already
+                    s[3] = ab2;
+                    s[4] = r2 * vfma(b_, vsplat(u, 2.0f), ab2);
+                } else {
+                    const F tn2 = (t * 2.0f) * nuv;
+                    s[3] = vfma(r2, np_, tn2);
+                    s[4] = r2 * (s[3] + tn2);
+                }
             } else {
 #pragma unroll
-                for (int j = 0; j < ND; ++j)             // dq/dk_j = (ds/dk_j) p + 2 (ds1/dk_j) t (u,v)   (:170-180)
-                    s[3 + j] = vfma(R.ds[j], np_, (R.ds1x2[j] * t) * nuv);
+                for (int j = 0; j < ND; ++j) {           // dq/dk_j = (ds/dk_j) p + 2 (ds1/dk_j) t (u,v)   (:170-180)
+                    if constexpr (LOGF && GCLM_REUSE_TNUV) s[3 + j] = vfma(R.ds[j], np_, R.ds1x2[j] * b_);       // t (n.uv) is there
+                    else s[3 + j] = vfma(R.ds[j], np_, (R.ds1x2[j] * t) * nuv);
+                }
             }
         }
         const F rho = vfma(ux, ry, -(uy * rx));
