@@ -30,8 +30,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
                 64 groups x 16 frames) at 5 steps after 2 warm-ups each, same event-based sweep timing, ground-truth check and
                 `check.vs_oracle` (64 images each); configs[3] also carries `slat_off`: the same solves on the same allocation
                 with the sin(latitude) scratch plane switched off (gclm_set_slat_plane(h, 0)) -- the plane's effect on THIS box;
-                and SURVEY 8(f)1's simple_divisional at B=1024 with `row_pairs_off`: the same solves with the one-row walk of the
-                sweep (gclm_set_row_pairs(h, 0)) -- the row-pair walk's effect on THIS box.
+                and SURVEY 8(f)1's radial and simple_divisional at B=1024, each with `row_pairs_off`: the same solves with the
+                one-row walk of the sweep (gclm_set_row_pairs(h, 0)) -- the row-pair walk's effect on THIS box.
   overlap:      N=1, independent intrinsics: the same batch solved as two halves on two side streams
                 (LMOptimizer.overlap_streams = 2, the library's default for large batches); `value` stays the one-stream run.
 The timed region (exactly --steps steps between barrier + synchronize) is run --repeats times; `value` and
@@ -728,6 +728,8 @@ def main():
                                               oracle_images=64 if args.cpu_sample != 0 else 0, slat_control=True),
             "shared16_pinhole": quick_case(lib, LMOptimizer, synth_fields, dev, "pinhole", B, H, W, args.lm_steps, args.seed, 16,
                                            oracle_images=64 if args.cpu_sample != 0 else 0),
+            f"radial_B{B}": quick_case(lib, LMOptimizer, synth_fields, dev, "radial", B, H, W, args.lm_steps, args.seed, 0,
+                                       oracle_images=64 if args.cpu_sample != 0 else 0, pairs_control=True),
             f"simple_divisional_B{B}": quick_case(lib, LMOptimizer, synth_fields, dev, "simple_divisional", B, H, W, args.lm_steps, args.seed, 0,
                                                   oracle_images=64 if args.cpu_sample != 0 else 0, pairs_control=True),
         }

@@ -29,6 +29,10 @@ print("run $i: %.0f img/s (%.3f ms), sweep %.4f = %.3f of this allocation's read
 print("       simple_radial %.0f (%.4f; plane off %.4f, on again %.4f, bits %s; %.3f of its ceiling; vs oracle %s) | shared16 %.0f (%.4f; %.3f of its ceiling; vs oracle %s) | cpu %s %.1f" % (
     sr["value"], sr["roofline"]["frac"], sr["slat_off"]["frac"], sr["slat_off"]["on_again"]["frac"], sr["slat_off"]["bit_identical"], sr["roofline"]["frac_of_read_ceiling"], vo(sr["check"]["vs_oracle"]),
     sh["value"], sh["roofline"]["frac"], sh["roofline"]["frac_of_read_ceiling"], vo(sh["check"]["vs_oracle"]), d["cpu_baseline"]["kind"], d["cpu_baseline"]["value"]))
+ra = s.get("radial_B1024")
+if ra:
+    print("       radial %.0f (%.4f; one-row walk %.0f / %.4f, row pairs again %.4f; %.3f of its ceiling; vs oracle %s)" % (
+        ra["value"], ra["roofline"]["frac"], ra["row_pairs_off"]["value"], ra["row_pairs_off"]["frac"], ra["row_pairs_off"]["on_again"]["frac"], ra["roofline"]["frac_of_read_ceiling"], vo(ra["check"]["vs_oracle"])))
 sd = s["simple_divisional_B1024"]; rp = sd["row_pairs_off"]; c = sd["check"]["vs_oracle"]
 ys = c.get("yardstick", {})
 print("       simple_divisional %.0f (%.4f; one-row walk %.0f / %.4f, row pairs again %.4f; vs oracle: %d of %d images within 1e-4, medians %.1e/%.1e/%.1e, worst %.1e/%.1e/%.1e; the oracle's own float32 vs float64 exceeds 1e-4 on %s images, %s of %d within 1e-4 + 10 x that)" % (

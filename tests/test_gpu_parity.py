@@ -1443,7 +1443,7 @@ def test_bench_single_gpu_line_carries_secondary_overlap_and_best_of_n(dev):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["streams"] == 1
     sec = out["secondary"]
-    assert set(sec) == {"simple_radial_B832", "shared16_pinhole", "simple_divisional_B832"}
+    assert set(sec) == {"simple_radial_B832", "shared16_pinhole", "radial_B832", "simple_divisional_B832"}
     for name, rec in sec.items():
         assert rec["value"] > 0 and rec["steps"] == 5 and rec["roofline"]["launches_timed"] == 5 * 21
         assert 0 < rec["roofline"]["frac"] < 1 and rec["check"]["median_focal_rel_err_vs_gt"] < 5e-3
@@ -1463,10 +1463,11 @@ def test_bench_single_gpu_line_carries_secondary_overlap_and_best_of_n(dev):
             assert max(vo["max_focal_rel"], vo["max_gravity_abs"], vo["max_final_cost_rel"]) <= 1e-4
         assert 0 < rec["roofline"]["frac"] <= rec["roofline"]["read_ceiling_frac"] * 1.02 <= 1.05
     # ... the control for the row-pair walk of simple_divisional's sweep: the same solves with the one-row walk, then the default again
-    sd = sec["simple_divisional_B832"]
-    rp = sd["row_pairs_off"]
-    assert rp["value"] > 0 and 0 < rp["frac"] < sd["roofline"]["frac"] and rp["on_again"]["frac"] > rp["frac"], (rp, sd["roofline"])
-    assert rp["median_focal_rel_vs_default"] < 1e-5 and rp["median_gravity_abs_vs_default"] < 1e-5, rp
+    for name in ("simple_divisional_B832", "radial_B832"):
+        sd = sec[name]
+        rp = sd["row_pairs_off"]
+        assert rp["value"] > 0 and 0 < rp["frac"] < sd["roofline"]["frac"] and rp["on_again"]["frac"] > rp["frac"], (name, rp, sd["roofline"])
+        assert rp["median_focal_rel_vs_default"] < 1e-5 and rp["median_gravity_abs_vs_default"] < 1e-5, (name, rp)
     assert "row_pairs_off" not in sec["simple_radial_B832"]
     # ... and the control for the scratch plane on the driver's own box: the same solves with the plane off, then on again
     sr = sec["simple_radial_B832"]
