@@ -1125,7 +1125,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& a, const PBlock& P, 
 }
 
 // launch bounds: radial / simple_divisional are held to 168 VGPRs (3 waves per SIMD); simple_radial reaches 112 (4 waves) on its
-// own; the log-focal pinhole sweep is held to 80 (6 waves); its general-focal instantiation would spill at 80 and keeps its own
+// own; the log-focal pinhole sweep is held to 80 (6 waves; its launches keep 3 resident: GCLM_PINHOLE_LDS); its general-focal instantiation would spill at 80 and keeps its own
 // 96, and so do its scratch-plane instantiations SLAT != 0 (never the library's built-in choice for pinhole)
 template <int MODEL, bool HAS_UP, bool HAS_UPC, bool HAS_LATC, bool LOGF, int VEC, int SLAT = 0, bool MIRROR = false>
 __global__ __launch_bounds__(kBlock, MIRROR ? (MODEL == GCLM_RADIAL && LOGF ? GCLM_MIRROR_WAVES_RADIAL : GCLM_MIRROR_WAVES) : (VEC == 4 && MODEL == GCLM_RADIAL) ? GCLM_RADIAL_WAVES : (VEC == 4 && MODEL > GCLM_RADIAL) ? GCLM_DIV_WAVES : (VEC == 4 && MODEL == GCLM_SIMPLE_RADIAL) ? 4 : (VEC == 4 && MODEL == GCLM_PINHOLE && LOGF) ? (SLAT == 0 ? GCLM_PINHOLE_WAVES : 5) : GCLM_MIN_WAVES) void sweep_kernel(
